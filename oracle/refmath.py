@@ -1,0 +1,369 @@
+"""PyTorch-CPU restatement of the reference hot path as pure functions over a flat weight dict.
+
+Every function takes `W`, a `{reference state_dict key: tensor}` mapping (optionally with a
+key prefix `p`), so the checkpoint key names of SURVEY.md section 5 are spelled out where
+they are used.  Autograd works through all of it (used for the gradient fixtures).
+
+Test infrastructure (see oracle/__init__.py); fp32 throughout like the reference.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------- primitives
+def step_embedding(t, dim=256):
+    """model/blocks.py:906-913 -- [sin | cos] of t * exp(-i ln(1e4)/(dim/2-1))."""
+    half = dim // 2
+    rate = math.log(10000) / (half - 1)
+    freq = torch.exp(torch.arange(half, device=t.device) * -rate)
+    ang = t[:, None] * freq[None, :]
+    return torch.cat((ang.sin(), ang.cos()), dim=-1)
+
+
+def mish(x):
+    """model/blocks.py:894-896."""
+    return x * torch.tanh(F.softplus(x))
+
+
+def _conv(W, name, x, stride=1, padding=0):
+    """ConvNorm (model/blocks.py:326-371): nn.Conv1d with bias; keys `<name>.conv.{weight,bias}`."""
+    return F.conv1d(x, W[name + ".conv.weight"], W[name + ".conv.bias"], stride=stride, padding=padding)
+
+
+def _lin(W, name, x):
+    """LinearNorm (model/blocks.py:278-291): bias-free nn.Linear; key `<name>.linear.weight`."""
+    return F.linear(x, W[name + ".linear.weight"])
+
+
+def extract(a, t, ndim):
+    """model/diffusion.py:26-29."""
+    return a.gather(-1, t).reshape(t.shape[0], *((1,) * (ndim - 1)))
+
+
+# ----------------------------------------------------------------------------- diffusion algebra
+def norm_spec(x, spec_min, spec_max):
+    """model/diffusion.py:228-229."""
+    return (x - spec_min) / (spec_max - spec_min) * 2 - 1
+
+
+def denorm_spec(x, spec_min, spec_max):
+    """model/diffusion.py:231-232."""
+    return (x + 1) / 2 * (spec_max - spec_min) + spec_min
+
+
+def q_sample(buf, x_start, t, noise):
+    """model/diffusion.py:147-153."""
+    return (extract(buf["sqrt_alphas_cumprod"], t, x_start.dim()) * x_start
+            + extract(buf["sqrt_one_minus_alphas_cumprod"], t, x_start.dim()) * noise)
+
+
+def diffuse_fn(buf, mel, t, noise):
+    """model/diffusion.py:177-185.  mel [B,L,M] -> [B,1,M,L]; rows with t<0 return the clean x0.
+
+    (The reference mutates `t` in place; callers pass temporaries, so a clone is equivalent.)
+    """
+    x0 = norm_spec(mel, buf["spec_min"], buf["spec_max"]).transpose(1, 2)[:, None, :, :]
+    neg = t < 0
+    tt = t.clone()
+    tt[neg] = 0
+    out = q_sample(buf, x0, tt, noise)
+    out[neg] = x0[neg]
+    return out
+
+
+def q_posterior_sample(buf, x_start, x_t, t, noise):
+    """model/diffusion.py:104-119."""
+    nd = x_t.dim()
+    mean = (extract(buf["posterior_mean_coef1"], t, nd) * x_start
+            + extract(buf["posterior_mean_coef2"], t, nd) * x_t)
+    logvar = extract(buf["posterior_log_variance_clipped"], t, nd)
+    gate = (1 - (t == 0).float()).reshape(x_start.shape[0], *((1,) * (nd - 1)))
+    return mean + gate * (0.5 * logvar).exp() * noise
+
+
+# ----------------------------------------------------------------------------- denoiser
+def resblock_forward(W, p, x, cond, step, spk=None):
+    """model/blocks.py:1157-1176.  Returns (x_next, skip)."""
+    d = _lin(W, p + "diffusion_projection", step).unsqueeze(-1)
+    c = _conv(W, p + "conditioner_projection", cond)
+    resid = x + d
+    h = resid + c
+    if (p + "speaker_projection.linear.weight") in W:
+        h = h + _lin(W, p + "speaker_projection", spk).unsqueeze(-1)
+    z = _conv(W, p + "conv_layer", h, padding=1)
+    g, f = torch.chunk(z, 2, dim=1)
+    y = torch.sigmoid(g) * torch.tanh(f)
+    o = _conv(W, p + "output_projection", y)
+    nx, skip = torch.chunk(o, 2, dim=1)
+    return (nx + resid) / math.sqrt(2.0), skip
+
+
+def denoiser_n_layers(W, p=""):
+    n = 0
+    while (p + "residual_layers.%d.conv_layer.conv.weight" % n) in W:
+        n += 1
+    return n
+
+
+def denoiser_forward(W, p, mel, t, cond, spk=None, stack_skips=True):
+    """model/modules.py:420-446.  mel [B,1,M,L], t int64 [B], cond [B,H,L] -> [B,1,M,L].
+
+    `stack_skips=True` reproduces the reference's `torch.stack(skip)` reduction (the op the
+    CPU baseline must pay for).
+    """
+    x = F.relu(_conv(W, p + "input_projection.0", mel[:, 0]))
+    x = F.relu(x)
+    s = step_embedding(t, W[p + "mlp.0.linear.weight"].shape[1])
+    s = _lin(W, p + "mlp.2", mish(_lin(W, p + "mlp.0", s)))
+    n = denoiser_n_layers(W, p)
+    skips = []
+    for i in range(n):
+        x, sk = resblock_forward(W, p + "residual_layers.%d." % i, x, cond, s, spk)
+        skips.append(sk)
+    if stack_skips:
+        x = torch.sum(torch.stack(skips), dim=0) / math.sqrt(n)
+    else:
+        acc = skips[0]
+        for sk in skips[1:]:
+            acc = acc + sk
+        x = acc / math.sqrt(n)
+    x = F.relu(_conv(W, p + "skip_projection", x))
+    x = _conv(W, p + "output_projection", x)
+    return x[:, None, :, :]
+
+
+# ----------------------------------------------------------------------------- GaussianDiffusion
+class NoiseTape:
+    """Replays pre-drawn tensors in call order (stands in for torch.randn*/randint)."""
+
+    def __init__(self, items):
+        self.items = list(items)
+        self.i = 0
+
+    def __call__(self, shape=None):
+        x = self.items[self.i]
+        self.i += 1
+        if shape is not None:
+            assert tuple(x.shape) == tuple(shape), (tuple(x.shape), tuple(shape))
+        return x
+
+
+def p_sample(W, buf, x_t, t, cond, spk, noise, clip=True):
+    """model/diffusion.py:121-129."""
+    with torch.no_grad():
+        x0 = denoiser_forward(W, "denoise_fn.", x_t, t, cond, spk)
+        if clip:
+            x0 = x0.clamp(-1.0, 1.0)
+        return q_posterior_sample(buf, x0, x_t, t, noise)
+
+
+def sampling(W, buf, cond, spk, T, tape, noise=None, keep_all=True):
+    """model/diffusion.py:155-165.  cond [B,H,L].  Returns the list of T+1 denormalised mels."""
+    B, _, L = cond.shape
+    M = buf["spec_min"].shape[-1]
+    xs = [tape((B, 1, M, L)) if noise is None else noise]
+    for i in reversed(range(T)):
+        t = torch.full((B,), i, dtype=torch.long)
+        xs.append(p_sample(W, buf, xs[-1], t, cond, spk, tape((B, 1, M, L))))
+    outs = [denorm_spec(x[:, 0].transpose(1, 2), buf["spec_min"], buf["spec_max"]) for x in xs]
+    return outs if keep_all else outs[-1:]
+
+
+def diffusion_forward(W, buf, model, T, mel, cond, spk, mel_mask, coarse_mel, tape, t=None, clip=True):
+    """model/diffusion.py:187-226.  `mel_mask` is True = pad on entry, as MixGANTTS passes it.
+
+    RNG order: t, noise(x_t), noise(x_{t-1}), noise(posterior) in training;
+    [noise(x_T)], then one noise per step at inference.  All taken from `tape` (t too unless given).
+    """
+    B = cond.shape[0]
+    valid = ~mel_mask.unsqueeze(-1)                       # [B,L,1] True = keep
+    condT = cond.transpose(1, 2)
+    if mel is None:
+        if model != "shallow":
+            start = None
+        else:
+            tt = torch.full((B,), T - 1, dtype=torch.long)
+            M = buf["spec_min"].shape[-1]
+            start = diffuse_fn(buf, coarse_mel, tt, tape((B, 1, M, cond.shape[1]))) \
+                * valid.unsqueeze(-1).transpose(1, -1)
+        x0 = sampling(W, buf, condT, spk, T, tape, noise=start)[-1] * valid
+        return x0, None, None, None, (None if model != "shallow" else tt)
+    vm = valid.unsqueeze(-1).transpose(1, -1)             # [B,1,1,L]
+    if t is None:
+        t = tape((B,))
+    shp = (B, 1, mel.shape[2], mel.shape[1])
+    x_t = diffuse_fn(buf, mel, t, tape(shp)) * vm
+    x_prev = diffuse_fn(buf, mel, t - 1, tape(shp)) * vm
+    x0 = denoiser_forward(W, "denoise_fn.", x_t, t, condT, spk) * vm
+    if clip:
+        x0 = x0.clamp(-1.0, 1.0)
+    if model != "shallow":
+        start = x0
+    else:
+        start = norm_spec(coarse_mel, buf["spec_min"], buf["spec_max"]).transpose(1, 2)[:, None, :, :]
+    x_prev_pred = q_posterior_sample(buf, start, x_t, t, tape(shp)) * vm
+    back = lambda a: a[:, 0].transpose(1, 2)
+    return back(x0), back(x_t), back(x_prev), back(x_prev_pred), t
+
+
+def diffuse_trace(buf, x_start, mask, T, tape):
+    """model/diffusion.py:167-175 (aux only).  mask True = pad."""
+    B, L, M = x_start.shape
+    keep = ~mask.unsqueeze(-1)
+    out = [norm_spec(x_start, buf["spec_min"], buf["spec_max"]).clamp(-1.0, 1.0) * keep]
+    for i in range(T):
+        t = torch.full((B,), i, dtype=torch.long)
+        out.append(diffuse_fn(buf, x_start, t, tape((B, 1, M, L)))[:, 0].transpose(1, 2) * keep)
+    return out
+
+
+# ----------------------------------------------------------------------------- JCU discriminator
+JCU_KERNELS = (3, 5, 5, 5, 3)
+JCU_STRIDES = (1, 2, 2, 1, 1)
+
+
+def jcu_forward(W, x_ts, x_t_prevs, s, t, kernels=JCU_KERNELS, strides=JCU_STRIDES, n_layer=3):
+    """model/mixgantts.py:256-288.  Returns (cond_feats[5], uncond_feats[5])."""
+    x = _lin(W, "input_projection", torch.cat([x_t_prevs, x_ts], dim=-1)).transpose(1, 2)
+    e = step_embedding(t, W["mlp.0.linear.weight"].shape[1])
+    e = _lin(W, "mlp.2", mish(_lin(W, "mlp.0", e))).unsqueeze(-1)
+    cond_feats, uncond_feats = [], []
+    for i in range(n_layer):
+        k = kernels[i]
+        x = F.leaky_relu(_conv(W, "conv_block.%d" % i, x, strides[i], (k - 1) // 2), 0.2)
+        cond_feats.append(x)
+        uncond_feats.append(x)
+    xc = x + e
+    if "spk_mlp.0.linear.weight" in W:
+        xc = xc + _lin(W, "spk_mlp.0", s).unsqueeze(-1)
+    xu = x
+    n_tail = len(kernels) - n_layer
+    for j in range(n_tail):
+        k = kernels[n_layer + j]
+        st = strides[n_layer + j]
+        xc = F.leaky_relu(_conv(W, "cond_conv_block.%d" % j, xc, st, (k - 1) // 2), 0.2)
+        cond_feats.append(xc)
+    for j in range(n_tail):
+        k = kernels[n_layer + j]
+        st = strides[n_layer + j]
+        xu = F.leaky_relu(_conv(W, "uncond_conv_block.%d" % j, xu, st, (k - 1) // 2), 0.2)
+        uncond_feats.append(xu)
+    return cond_feats, uncond_feats
+
+
+# ----------------------------------------------------------------------------- losses on the path
+def jcu_lsgan(logit_c, logit_u, target):
+    """model/loss.py:14-19 (mask=None branch, the only one train.py uses)."""
+    lc = F.mse_loss(logit_c, torch.full_like(logit_c, target))
+    lu = F.mse_loss(logit_u, torch.full_like(logit_u, target))
+    return 0.5 * (lc + lu)
+
+
+def d_loss(real_c, real_u, fake_c, fake_u):
+    """model/loss.py:21-24."""
+    return jcu_lsgan(real_c, real_u, 1.0), jcu_lsgan(fake_c, fake_u, 0.0)
+
+
+def g_loss(fake_c, fake_u):
+    """model/loss.py:26-28."""
+    return jcu_lsgan(fake_c, fake_u, 1.0)
+
+
+def fm_loss(real_c, real_u, fake_c, fake_u, n_layers=5):
+    """model/loss.py:221-227: sum_{j<len-1} (4/(n_layers+1)) * 0.5 * (L1 + L1); unscaled by lambda_fm."""
+    w = 4.0 / (n_layers + 1)
+    tot = 0
+    for j in range(len(fake_c) - 1):
+        tot = tot + w * 0.5 * (F.l1_loss(real_c[j].detach(), fake_c[j]) + F.l1_loss(real_u[j].detach(), fake_u[j]))
+    return tot
+
+
+def mel_l1(pred, target, pad_mask):
+    """model/loss.py:229-242,255-259: masked_fill pads with 0, L1 weighted by non-zero target rows."""
+    pred = pred.masked_fill(pad_mask.unsqueeze(-1), 0)
+    target = target.masked_fill(pad_mask.unsqueeze(-1), 0)
+    per = F.l1_loss(pred, target, reduction="none")
+    w = target.abs().sum(-1, keepdim=True).ne(0).float().repeat(1, 1, target.size(-1))
+    return (per * w).sum() / w.sum()
+
+
+# ----------------------------------------------------------------------------- FFT blocks (shallow / aux)
+def sinusoid_table(n_position, d_hid):
+    """transformer/Models.py:10-30 (float64 numpy semantics, cast to fp32)."""
+    pos = torch.arange(n_position, dtype=torch.float64)[:, None]
+    j = torch.arange(d_hid, dtype=torch.float64)[None, :]
+    ang = pos / torch.pow(torch.tensor(10000.0, dtype=torch.float64), 2 * torch.div(j, 2, rounding_mode="floor") / d_hid)
+    tab = torch.zeros(n_position, d_hid, dtype=torch.float64)
+    tab[:, 0::2] = torch.sin(ang[:, 0::2])
+    tab[:, 1::2] = torch.cos(ang[:, 1::2])
+    return tab.float()
+
+
+def mha_forward(W, p, x, pad_mask, n_head=2):
+    """transformer/SubLayers.py:29-57 + Modules.py:16-23 (eval: dropout = identity).
+
+    x [B,L,D]; pad_mask bool [B,L] True = pad (keys masked with -inf for every query row).
+    """
+    B, L, D = x.shape
+    dk = D // n_head
+    lin = lambda n, a: F.linear(a, W[p + n + ".weight"], W[p + n + ".bias"])
+    heads = lambda a: a.view(B, L, n_head, dk).permute(2, 0, 1, 3).reshape(n_head * B, L, dk)
+    q, k, v = heads(lin("w_qs", x)), heads(lin("w_ks", x)), heads(lin("w_vs", x))
+    att = torch.bmm(q, k.transpose(1, 2)) / (dk ** 0.5)
+    km = pad_mask.unsqueeze(1).expand(-1, L, -1).repeat(n_head, 1, 1)
+    att = torch.softmax(att.masked_fill(km, float("-inf")), dim=2)
+    o = torch.bmm(att, v).view(n_head, B, L, dk).permute(1, 2, 0, 3).reshape(B, L, D)
+    o = lin("fc", o)
+    return F.layer_norm(o + x, (D,), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], 1e-5)
+
+
+def ffn_forward(W, p, x):
+    """transformer/SubLayers.py:85-93 (eval)."""
+    D = x.shape[-1]
+    k = W[p + "w_1.weight"].shape[-1]
+    h = F.relu(F.conv1d(x.transpose(1, 2), W[p + "w_1.weight"], W[p + "w_1.bias"], padding=(k - 1) // 2))
+    o = F.conv1d(h, W[p + "w_2.weight"], W[p + "w_2.bias"]).transpose(1, 2)
+    return F.layer_norm(o + x, (D,), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], 1e-5)
+
+
+def fft_block(W, p, x, pad_mask, n_head=2):
+    """transformer/Layers.py:21-30."""
+    y = mha_forward(W, p + "slf_attn.", x, pad_mask, n_head).masked_fill(pad_mask.unsqueeze(-1), 0)
+    return ffn_forward(W, p + "pos_ffn.", y).masked_fill(pad_mask.unsqueeze(-1), 0)
+
+
+def decoder_forward(W, p, x, pad_mask, max_seq_len, n_layers=6, n_head=2, training=False):
+    """transformer/Models.py:139-171."""
+    B, L, D = x.shape
+    if (not training) and L > max_seq_len:
+        y = x + sinusoid_table(L, D)[None, :L, :]
+    else:
+        L = min(L, max_seq_len)
+        y = x[:, :L, :] + W[p + "position_enc"][:, :L, :]
+        pad_mask = pad_mask[:, :L]
+    for i in range(n_layers):
+        y = fft_block(W, p + "layer_stack.%d." % i, y, pad_mask, n_head)
+    return y
+
+
+def postnet_forward(W, p, x, n_conv=5):
+    """transformer/Layers.py:129-137 in eval mode (BatchNorm running stats, dropout off)."""
+    y = x.transpose(1, 2)
+    for i in range(n_conv):
+        c = p + "convolutions.%d." % i
+        k = W[c + "0.conv.weight"].shape[-1]
+        y = F.conv1d(y, W[c + "0.conv.weight"], W[c + "0.conv.bias"], padding=(k - 1) // 2)
+        y = F.batch_norm(y, W[c + "1.running_mean"], W[c + "1.running_var"], W[c + "1.weight"], W[c + "1.bias"],
+                         False, 0.1, 1e-5)
+        if i < n_conv - 1:
+            y = torch.tanh(y)
+    return y.transpose(1, 2)
+
+
+def coarse_mel(W, x, pad_mask, max_seq_len, n_layers=6, n_head=2):
+    """model/mixgantts.py:140-143: Decoder -> mel_linear -> PostNet residual."""
+    h = decoder_forward(W, "decoder.", x, pad_mask, max_seq_len, n_layers, n_head)
+    m = F.linear(h, W["mel_linear.weight"], W["mel_linear.bias"])
+    return postnet_forward(W, "postnet.", m) + m

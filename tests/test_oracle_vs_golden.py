@@ -1,0 +1,198 @@
+"""Pins oracle/ (the CPU restatement) to outputs of the REAL reference (tests/golden/*.npz,
+made by tools/make_golden.py from /root/reference).  CPU only; tolerance 2e-6 relative for
+fp32 forwards (same ATen ops, different association in a few places), 2e-5 for gradients.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden, T, seeded, assert_close, assert_digest
+from oracle import schedule as S, refmath as R
+
+FWD = 2e-6
+BWD = 2e-5
+
+
+def _buf(mode="vpsde", Tn=4, g=None):
+    b = {k: T(v) for k, v in S.diffusion_buffers(S.beta_schedule(mode, Tn, 0.1, 40, 0.008)).items()}
+    if g is not None:
+        b["spec_min"] = T(g["spec_min"])[None, None, :]
+        b["spec_max"] = T(g["spec_max"])[None, None, :]
+    return b
+
+
+def test_schedule_buffers_match_reference():
+    g = golden("schedule")
+    for mode, Tn in [("vpsde", 1), ("vpsde", 4), ("vpsde", 100), ("vpsde", 1000), ("linear", 4), ("cosine", 4)]:
+        with np.errstate(all="ignore"):
+            b = S.diffusion_buffers(S.beta_schedule(mode, Tn, 0.1, 40, 0.008))
+        for k in S.BUFFER_NAMES:
+            ref = g["%s_%d/%s" % (mode, Tn, k)]
+            np.testing.assert_array_equal(b[k], ref, err_msg="%s T=%d %s" % (mode, Tn, k))  # bit-exact, NaN==NaN
+
+
+def test_schedule_known_values():
+    # SURVEY.md section 8 a2 probe values for T=4 vpsde
+    b = S.diffusion_buffers(S.beta_schedule("vpsde", 4, 0.1, 40, 0.008))
+    np.testing.assert_allclose(b["alphas_cumprod"], [0.2803, 6.49e-3, 1.24e-5, 1.96e-9], rtol=2e-3)
+    assert abs(b["posterior_log_variance_clipped"][0] - (-46.0517)) < 1e-3
+
+
+def test_step_embedding():
+    g = golden("step_embedding")
+    assert_close(R.step_embedding(T(g["t"])), g["emb"], 1e-6, "step_embedding")
+
+
+def test_elementwise():
+    g = golden("elementwise")
+    b = _buf(g=g)
+    mel, noise, x0, xt = T(g["mel"]), T(g["noise"]), T(g["x0"]), T(g["xt"])
+    assert_close(R.norm_spec(mel, b["spec_min"], b["spec_max"]), g["norm"], 1e-6, "norm")
+    assert_close(R.denorm_spec(x0[:, 0].transpose(1, 2), b["spec_min"], b["spec_max"]), g["denorm"], 1e-6, "denorm")
+    assert_close(R.q_sample(b, x0, T(g["tq"]), noise), g["q_sample"], 1e-6, "q_sample")
+    assert_close(R.diffuse_fn(b, mel, T(g["td"]), noise), g["diffuse"], 1e-6, "diffuse_fn")
+    assert_close(R.q_posterior_sample(b, x0, xt, T(g["tp"]), T(g["post_noise"])), g["post"], 1e-6, "posterior")
+
+
+@pytest.mark.parametrize("ms", [0, 1])
+def test_resblock(manifest, ms):
+    name = "resblock_ms%d" % ms
+    g = golden(name)
+    W, ck = seeded(manifest, name, 11 + ms, requires_grad=True)
+    np.testing.assert_allclose(ck, g["wsum"], rtol=1e-12)
+    x, cond, step = (T(g[k]).requires_grad_() for k in ("x", "cond", "step"))
+    spk = T(g["spk"]).requires_grad_() if ms else None
+    nx, sk = R.resblock_forward(W, "", x, cond, step, spk)
+    assert_close(nx, g["out_x"], FWD, "x")
+    assert_close(sk, g["out_skip"], FWD, "skip")
+    ((nx * T(g["gx"])).sum() + (sk * T(g["gs"])).sum()).backward()
+    assert_close(x.grad, g["d_x"], BWD, "d_x")
+    assert_close(cond.grad, g["d_cond"], BWD, "d_cond")
+    assert_close(step.grad, g["d_step"], BWD, "d_step")
+    if ms:
+        assert_close(spk.grad, g["d_spk"], BWD, "d_spk")
+    for k, w in W.items():
+        assert_digest(w.grad, g, k, BWD)
+
+
+@pytest.mark.parametrize("ms", [0, 1])
+def test_denoiser(manifest, ms):
+    name = "denoiser_ms%d" % ms
+    g = golden(name)
+    W, ck = seeded(manifest, name, 21 + ms, requires_grad=True)
+    np.testing.assert_allclose(ck, g["wsum"], rtol=1e-12)
+    x, cond = T(g["x"]).requires_grad_(), T(g["cond"]).requires_grad_()
+    spk = T(g["spk"]).requires_grad_() if ms else None
+    out = R.denoiser_forward(W, "", x, T(g["t"]), cond, spk)
+    assert_close(out, g["out"], FWD, "denoiser out")
+    # the running-sum skip reduction is the same function up to fp32 association
+    out2 = R.denoiser_forward(W, "", x, T(g["t"]), cond, spk, stack_skips=False)
+    assert_close(out2, g["out"], 1e-5, "denoiser out (running skip sum)")
+    (out * T(g["go"])).sum().backward()
+    assert_close(x.grad, g["d_x"], BWD, "d_x")
+    assert_close(cond.grad, g["d_cond"], BWD, "d_cond")
+    if ms:
+        assert_close(spk.grad, g["d_spk"], BWD, "d_spk")
+    for k, w in W.items():
+        assert_digest(w.grad, g, k, 5e-5)
+
+
+@pytest.mark.parametrize("model,ms", [("naive", 0), ("naive", 1), ("shallow", 0)])
+def test_gaussian_diffusion(manifest, model, ms):
+    name = "diffusion_%s_ms%d" % (model, ms)
+    g = golden(name)
+    W, ck = seeded(manifest, name, 31 + ms, requires_grad=True)
+    np.testing.assert_allclose(ck, g["wsum"], rtol=1e-12)
+    e = golden("elementwise")
+    b = _buf(g=e)
+    mel, pad = T(g["mel"]), T(g["pad"])
+    cond = T(g["cond"]).requires_grad_()
+    spk = T(g["spk"]) if ms else None
+    coarse = T(g["coarse"]) if model == "shallow" else None
+    tape = R.NoiseTape([T(g["t"]), T(g["n_xt"]), T(g["n_prev"]), T(g["n_post"])])
+    x0p, x_t, x_prev, x_pp, t = R.diffusion_forward(W, b, model, 4, mel, cond, spk, pad, coarse, tape)
+    assert_close(x_t, g["x_t"], 1e-6, "x_t")
+    assert_close(x_prev, g["x_prev"], 1e-6, "x_prev")
+    assert_close(x0p, g["x0_pred"], FWD, "x0_pred")
+    assert_close(x_pp, g["x_prev_pred"], FWD, "x_prev_pred")
+    ((x0p * T(g["w1"])).sum() + (x_pp * T(g["w2"])).sum()).backward()
+    assert_close(cond.grad, g["d_cond"], BWD, "d_cond")
+    for k in [k[len("dw_sum/"):] for k in g if k.startswith("dw_sum/")]:
+        assert_digest(W[k].grad, g, k, 5e-5)
+    # inference branch
+    n_inf = sorted(k for k in g if k.startswith("infer_noise"))
+    tape = R.NoiseTape([T(g[k]) for k in n_inf])
+    Wd = {k: v.detach() for k, v in W.items()}
+    y, *_ = R.diffusion_forward(Wd, b, model, 4, None, cond.detach(), spk, pad, coarse, tape)
+    assert_close(y, g["infer_out"], 1e-5, "inference mel")
+    # sampling() list (T+1 entries)
+    n_s = sorted(k for k in g if k.startswith("sampling_noise"))
+    tape = R.NoiseTape([T(g[k]) for k in n_s])
+    ys = R.sampling(Wd, b, cond.detach().transpose(1, 2), spk, 4, tape)
+    assert_close(torch.stack(ys), g["sampling_list"], 1e-5, "sampling list")
+    if model == "shallow":
+        tape = R.NoiseTape([T(g[k]) for k in sorted(k for k in g if k.startswith("trace_noise"))])
+        tr = R.diffuse_trace(b, coarse, pad, 4, tape)
+        assert_close(torch.stack(tr), g["trace"], 1e-6, "diffuse_trace")
+
+
+@pytest.mark.parametrize("ms", [0, 1])
+@pytest.mark.parametrize("L", [37, 64])
+def test_jcu_and_losses(manifest, ms, L):
+    g = golden("jcu_ms%d_L%d" % (ms, L))
+    W, ck = seeded(manifest, "jcu_ms%d" % ms, 41 + ms, requires_grad=True)
+    np.testing.assert_allclose(ck, g["wsum"], rtol=1e-12)
+    x_ts, fake = T(g["x_ts"]).requires_grad_(), T(g["fake"]).requires_grad_()
+    real, t = T(g["real"]), T(g["t"])
+    s = T(g["s"]) if ms else None
+    fc, fu = R.jcu_forward(W, x_ts, fake, s, t)
+    rc, ru = R.jcu_forward(W, x_ts, real, s, t)
+    for i in range(5):
+        assert_close(fc[i], g["fc%d" % i], 5e-6, "fc%d" % i)
+        assert_close(fu[i], g["fu%d" % i], 5e-6, "fu%d" % i)
+        assert_close(rc[i], g["rc%d" % i], 5e-6, "rc%d" % i)
+        assert_close(ru[i], g["ru%d" % i], 5e-6, "ru%d" % i)
+    r_loss, f_loss = R.d_loss(rc[-1], ru[-1], fc[-1], fu[-1])
+    adv = R.g_loss(fc[-1], fu[-1])
+    fm = R.fm_loss(rc, ru, fc, fu)
+    for a, k in ((r_loss, "r_loss"), (f_loss, "f_loss"), (adv, "adv"), (fm, "fm")):
+        assert abs(a.item() - float(g[k])) <= 5e-6 * max(1.0, abs(float(g[k]))), k
+    (r_loss + f_loss + adv + 10.0 * fm).backward()
+    assert_close(x_ts.grad, g["d_x_ts"], BWD, "d_x_ts")
+    assert_close(fake.grad, g["d_fake"], BWD, "d_fake")
+    for k, w in W.items():
+        assert_digest(w.grad, g, k, 5e-5)
+
+
+def test_mel_l1():
+    g = golden("mel_loss")
+    v = R.mel_l1(T(g["pred"]), T(g["targ"]), T(g["pad"]))
+    assert abs(v.item() - float(g["loss"])) < 1e-6
+
+
+def test_fftblock(manifest):
+    g = golden("fftblock")
+    W, ck = seeded(manifest, "fftblock", 51, requires_grad=True)
+    np.testing.assert_allclose(ck, g["wsum"], rtol=1e-12)
+    x = T(g["x"]).requires_grad_()
+    y = R.fft_block(W, "", x, T(g["pad"]))
+    assert_close(y, g["out"], 5e-6, "fft out")
+    (y * T(g["go"])).sum().backward()
+    assert_close(x.grad, g["d_x"], BWD, "fft d_x")
+    for k, w in W.items():
+        assert_digest(w.grad, g, k, 5e-5)
+
+
+def test_decoder_and_postnet(manifest):
+    g = golden("decoder")
+    W, ck = seeded(manifest, "decoder", 52)
+    np.testing.assert_allclose(ck, g["wsum"], rtol=1e-12)
+    msl = int(g["max_seq_len"])
+    W["position_enc"] = R.sinusoid_table(msl + 1, 256)[None]
+    for tag in ("short", "long"):
+        y = R.decoder_forward(W, "", T(g[tag + "_x"]), T(g[tag + "_pad"]), msl)
+        assert_close(y, g[tag + "_out"], 1e-5, "decoder " + tag)
+    g = golden("postnet")
+    W, ck = seeded(manifest, "postnet", 53)
+    np.testing.assert_allclose(ck, g["wsum"], rtol=1e-12)
+    assert_close(R.postnet_forward(W, "", T(g["x"])), g["out"], 5e-6, "postnet")

@@ -1,0 +1,390 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (/root/reference) on CPU.
+
+Run in the build container only:   python tools/make_golden.py
+The reference source never leaves this container; only inputs/outputs (data) are written.
+Weights are not stored: they are re-drawn on both sides by oracle/weights.py from the
+state_dict manifest kept in tests/golden/manifest.json.
+
+Cases follow SURVEY.md section 8c (i)-(ix).
+"""
+import contextlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_harness as H  # noqa: E402
+
+H.install_stubs()
+import torch  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+from model.diffusion import GaussianDiffusion  # noqa: E402
+from model.modules import Denoiser  # noqa: E402
+from model.blocks import ResidualBlock, DiffusionEmbedding  # noqa: E402
+from model.mixgantts import JCUDiscriminator  # noqa: E402
+from model import loss as ref_loss  # noqa: E402
+from transformer import Decoder, PostNet  # noqa: E402
+from transformer.Layers import FFTBlock  # noqa: E402
+
+from oracle import weights as WR  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+MANIFEST = {}
+
+
+def manifest_of(mod):
+    """Trainable parameters + BatchNorm running stats, i.e. everything the recipe draws."""
+    m = {}
+    for k, p in mod.named_parameters():
+        if p.requires_grad:
+            m[k] = list(p.shape)
+    for k, b in mod.named_buffers():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            m[k] = list(b.shape)
+    return m
+
+
+def seed_module(mod, seed, name):
+    man = manifest_of(mod)
+    MANIFEST[name] = {"seeded": man,
+                      "state_dict": {k: list(v.shape) for k, v in mod.state_dict().items()}}
+    w = WR.draw(man, seed)
+    sd = mod.state_dict()
+    with torch.no_grad():
+        for k, a in w.items():
+            sd[k].copy_(torch.from_numpy(a))
+    return WR.checksum(w)
+
+
+class Tape:
+    """Deterministic stand-in for torch.randn / randn_like / randint inside the reference."""
+
+    def __init__(self, rng, T):
+        self.rng = rng
+        self.T = T
+        self.log = []
+        self.forced_t = None
+
+    def randn(self, *shape, **kw):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+            shape = tuple(shape[0])
+        a = torch.from_numpy(self.rng.standard_normal(shape).astype(np.float32))
+        self.log.append(a.numpy().copy())
+        return a
+
+    def randn_like(self, x, **kw):
+        return self.randn(tuple(x.shape))
+
+    def randint(self, lo, hi, shape, **kw):
+        if self.forced_t is not None:
+            a = torch.as_tensor(self.forced_t, dtype=torch.long).clone()
+        else:
+            a = torch.from_numpy(self.rng.integers(lo, hi, size=tuple(shape)).astype(np.int64))
+        self.log.append(a.numpy().copy())
+        return a
+
+
+@contextlib.contextmanager
+def patched_rng(tape):
+    saved = (torch.randn, torch.randn_like, torch.randint)
+    torch.randn, torch.randn_like, torch.randint = tape.randn, tape.randn_like, tape.randint
+    try:
+        yield tape
+    finally:
+        torch.randn, torch.randn_like, torch.randint = saved
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    clean = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        clean[k] = np.asarray(v)
+    np.savez_compressed(path, **clean)
+    sz = os.path.getsize(path)
+    print("  wrote %-40s %8.1f KB" % (os.path.basename(path), sz / 1024))
+
+
+def configs(model="naive", T=4, mode="vpsde", multi_speaker=False, stats_dir=None, max_seq_len=None):
+    pre, mc, tr = H.load_configs("LJSpeech")
+    mc["denoiser"]["noise_schedule_naive"] = mode
+    mc["denoiser"]["timesteps"] = T
+    mc["denoiser"]["shallow_timesteps"] = T
+    mc["multi_speaker"] = multi_speaker
+    if max_seq_len is not None:
+        mc["max_seq_len"] = max_seq_len
+    pre["path"]["preprocessed_path"] = stats_dir
+    return types.SimpleNamespace(model=model), pre, mc, tr
+
+
+def grad_digest(g):
+    """Small summary of a big gradient: fp64 sum, abs-sum and a fixed corner slice."""
+    g = g.detach().double()
+    corner = g[tuple(slice(0, min(4, s)) for s in g.shape)].float().numpy()
+    return np.array([g.sum().item(), g.abs().sum().item()]), corner
+
+
+# --------------------------------------------------------------------------------------------
+def main():
+    rng = np.random.default_rng(20240607)
+    M = 80
+    spec_min = np.linspace(-11.5, -9.0, M)
+    spec_max = np.linspace(1.0, 2.0, M)
+    stats = H.make_stats_dir(spec_min, spec_max, n_speakers=5)
+
+    # (i) schedules ---------------------------------------------------------------------------
+    print("schedules")
+    sched = {}
+    for mode, T in [("vpsde", 1), ("vpsde", 4), ("vpsde", 100), ("vpsde", 1000), ("linear", 4), ("cosine", 4)]:
+        gd = GaussianDiffusion(*configs("naive", T, mode, stats_dir=stats))
+        for k, v in gd.named_buffers():
+            if "denoise_fn" in k:
+                continue
+            sched["%s_%d/%s" % (mode, T, k)] = v.numpy().copy()
+    save("schedule", **sched)
+
+    # (ii) step embedding ---------------------------------------------------------------------
+    t = torch.tensor([0, 1, 3, 99, 999], dtype=torch.long)
+    save("step_embedding", t=t, emb=DiffusionEmbedding(256)(t))
+
+    # (iii) elementwise diffusion algebra ------------------------------------------------------
+    print("elementwise")
+    gd = GaussianDiffusion(*configs("naive", 4, stats_dir=stats))
+    B, L = 3, 37
+    mel = torch.from_numpy(rng.uniform(-11.5, 2.0, (B, L, M)).astype(np.float32))
+    noise = torch.from_numpy(rng.standard_normal((B, 1, M, L)).astype(np.float32))
+    x0 = torch.from_numpy(rng.uniform(-1, 1, (B, 1, M, L)).astype(np.float32))
+    xt = torch.from_numpy(rng.standard_normal((B, 1, M, L)).astype(np.float32))
+    tq = torch.tensor([3, 0, 2], dtype=torch.long)
+    td = torch.tensor([1, -1, 3], dtype=torch.long)
+    tp = torch.tensor([0, 2, 3], dtype=torch.long)
+    tape = Tape(rng, 4)
+    with patched_rng(tape):
+        post = gd.q_posterior_sample(x0, xt, tp)
+    save("elementwise", mel=mel, noise=noise, x0=x0, xt=xt, tq=tq, td=td, tp=tp,
+         norm=gd.norm_spec(mel), denorm=gd.denorm_spec(x0[:, 0].transpose(1, 2)),
+         q_sample=gd.q_sample(x0, tq, noise), diffuse=gd.diffuse_fn(mel, td.clone(), noise),
+         post_noise=tape.log[0], post=post, spec_min=spec_min.astype(np.float32), spec_max=spec_max.astype(np.float32))
+
+    # (iv) one residual block -----------------------------------------------------------------
+    print("resblock")
+    for ms in (False, True):
+        blk = ResidualBlock(256, 256, dropout=0.2, multi_speaker=ms)
+        name = "resblock_ms%d" % int(ms)
+        ck = seed_module(blk, 11 + int(ms), name)
+        B, L = 2, 37
+        x = torch.from_numpy(rng.standard_normal((B, 256, L)).astype(np.float32)).requires_grad_()
+        cond = torch.from_numpy(rng.standard_normal((B, 256, L)).astype(np.float32)).requires_grad_()
+        step = torch.from_numpy(rng.standard_normal((B, 256)).astype(np.float32)).requires_grad_()
+        spk = torch.from_numpy(rng.standard_normal((B, 256)).astype(np.float32)).requires_grad_() if ms else None
+        gx = torch.from_numpy(rng.standard_normal((B, 256, L)).astype(np.float32))
+        gs = torch.from_numpy(rng.standard_normal((B, 256, L)).astype(np.float32))
+        nx, sk = blk(x, cond, step, spk)
+        ((nx * gx).sum() + (sk * gs).sum()).backward()
+        arrs = dict(x=x, cond=cond, step=step, gx=gx, gs=gs, out_x=nx, out_skip=sk,
+                    d_x=x.grad, d_cond=cond.grad, d_step=step.grad, wsum=ck)
+        if ms:
+            arrs.update(spk=spk, d_spk=spk.grad)
+        for k, p in blk.named_parameters():
+            dg, corner = grad_digest(p.grad)
+            arrs["dw_sum/" + k] = dg
+            arrs["dw_corner/" + k] = corner
+        save(name, **arrs)
+
+    # (v) full denoiser -----------------------------------------------------------------------
+    print("denoiser")
+    for ms in (False, True):
+        _, pre, mc, _ = configs("naive", 4, multi_speaker=ms, stats_dir=stats)
+        den = Denoiser(pre, mc)
+        name = "denoiser_ms%d" % int(ms)
+        ck = seed_module(den, 21 + int(ms), name)
+        B, L = 2, 64
+        x = torch.from_numpy(rng.standard_normal((B, 1, M, L)).astype(np.float32)).requires_grad_()
+        cond = torch.from_numpy(rng.standard_normal((B, 256, L)).astype(np.float32)).requires_grad_()
+        spk = torch.from_numpy(rng.standard_normal((B, 256)).astype(np.float32)).requires_grad_() if ms else None
+        t = torch.tensor([3, 0], dtype=torch.long)
+        go = torch.from_numpy(rng.standard_normal((B, 1, M, L)).astype(np.float32))
+        out = den(x, t, cond, spk)
+        (out * go).sum().backward()
+        arrs = dict(x=x, cond=cond, t=t, go=go, out=out, d_x=x.grad, d_cond=cond.grad, wsum=ck)
+        if ms:
+            arrs.update(spk=spk, d_spk=spk.grad)
+        for k, p in den.named_parameters():
+            dg, corner = grad_digest(p.grad)
+            arrs["dw_sum/" + k] = dg
+            if k.startswith(("residual_layers.0.", "residual_layers.19.", "mlp.", "input_projection", "skip_projection",
+                             "output_projection")):
+                arrs["dw_corner/" + k] = corner
+        save(name, **arrs)
+
+    # (vi) GaussianDiffusion.forward / sampling --------------------------------------------------
+    print("diffusion forward")
+    for model in ("naive", "shallow"):
+        for ms in (False, True):
+            if model == "shallow" and ms:
+                continue
+            T = 4
+            gd = GaussianDiffusion(*configs(model, T, multi_speaker=ms, stats_dir=stats))
+            name = "diffusion_%s_ms%d" % (model, int(ms))
+            ck = seed_module(gd, 31 + int(ms), name)
+            B, L = 3, 48
+            lens = torch.tensor([48, 33, 40])
+            pad = torch.arange(L)[None, :] >= lens[:, None]          # True = pad, as MixGANTTS passes it
+            mel = torch.from_numpy(rng.uniform(-11.5, 2.0, (B, L, M)).astype(np.float32))
+            mel = mel.masked_fill(pad.unsqueeze(-1), 0.0)
+            cond = torch.from_numpy(rng.standard_normal((B, L, 256)).astype(np.float32)).requires_grad_()
+            spk = torch.from_numpy(rng.standard_normal((B, 256)).astype(np.float32)) if ms else None
+            coarse = torch.from_numpy(rng.uniform(-11.0, 1.5, (B, L, M)).astype(np.float32)) if model == "shallow" else None
+            tape = Tape(rng, T)
+            tape.forced_t = [2, 0, 3]
+            gd.train()
+            with patched_rng(tape):
+                x0p, x_t, x_prev, x_prev_pred, t = gd(mel, cond, spk, pad, coarse)
+            w1 = torch.from_numpy(rng.standard_normal(tuple(x0p.shape)).astype(np.float32))
+            w2 = torch.from_numpy(rng.standard_normal(tuple(x0p.shape)).astype(np.float32))
+            ((x0p * w1).sum() + (x_prev_pred * w2).sum()).backward()
+            arrs = dict(mel=mel, cond=cond, pad=pad, t=t, n_xt=tape.log[1], n_prev=tape.log[2], n_post=tape.log[3],
+                        x0_pred=x0p, x_t=x_t, x_prev=x_prev, x_prev_pred=x_prev_pred, w1=w1, w2=w2,
+                        d_cond=cond.grad, wsum=ck)
+            for k, p in gd.named_parameters():
+                if p.grad is not None and k.startswith(("denoise_fn.residual_layers.7.", "denoise_fn.output_projection")):
+                    dg, corner = grad_digest(p.grad)
+                    arrs["dw_sum/" + k] = dg
+                    arrs["dw_corner/" + k] = corner
+            if ms:
+                arrs["spk"] = spk
+            if coarse is not None:
+                arrs["coarse"] = coarse
+            # inference branch (sampling): uses the cond/spk stashed by the call above too
+            gd.eval()
+            tape2 = Tape(rng, T)
+            with patched_rng(tape2), torch.no_grad():
+                y, *_ = gd(None, cond.detach(), spk, pad, coarse)
+            arrs["infer_out"] = y
+            for i, a in enumerate(tape2.log):
+                arrs["infer_noise%d" % i] = a
+            # sampling() with no args from the stash, full list
+            tape3 = Tape(rng, T)
+            with patched_rng(tape3), torch.no_grad():
+                ys = gd.sampling()
+            arrs["sampling_list"] = torch.stack(ys)
+            for i, a in enumerate(tape3.log):
+                arrs["sampling_noise%d" % i] = a
+            if model == "shallow":
+                tape4 = Tape(rng, T)
+                with patched_rng(tape4), torch.no_grad():
+                    tr = gd.diffuse_trace(coarse, pad)
+                arrs["trace"] = torch.stack(tr)
+                for i, a in enumerate(tape4.log):
+                    arrs["trace_noise%d" % i] = a
+            save(name, **arrs)
+
+    # (vii) JCU discriminator + (viii) losses ----------------------------------------------------
+    print("jcu")
+    for ms in (False, True):
+        for L in (37, 64):
+            _, pre, mc, tr = configs("naive", 4, multi_speaker=ms, stats_dir=stats)
+            D = JCUDiscriminator(pre, mc, tr)
+            name = "jcu_ms%d_L%d" % (int(ms), L)
+            ck = seed_module(D, 41 + int(ms), "jcu_ms%d" % int(ms))
+            B = 2
+            x_ts = torch.from_numpy(rng.standard_normal((B, L, M)).astype(np.float32)).requires_grad_()
+            fake = torch.from_numpy(rng.standard_normal((B, L, M)).astype(np.float32)).requires_grad_()
+            real = torch.from_numpy(rng.standard_normal((B, L, M)).astype(np.float32))
+            s = torch.from_numpy(rng.standard_normal((B, 256)).astype(np.float32)) if ms else None
+            t = torch.tensor([1, 3], dtype=torch.long)
+            fc, fu = D(x_ts, fake, s, t)
+            rc, ru = D(x_ts, real, s, t)
+            d_fn, g_fn = ref_loss.get_adversarial_losses_fn("lsgan")
+            r_loss, f_loss = d_fn(rc[-1], ru[-1], fc[-1], fu[-1])
+            adv = g_fn(fc[-1], fu[-1])
+            holder = types.SimpleNamespace(n_layers=mc["discriminator"]["n_layer"] + mc["discriminator"]["n_cond_layer"])
+            fm = ref_loss.MixGANTTSLoss.get_fm_loss(holder, rc, ru, fc, fu)
+            total = r_loss + f_loss + adv + 10.0 * fm
+            total.backward()
+            arrs = dict(x_ts=x_ts, fake=fake, real=real, t=t, r_loss=r_loss, f_loss=f_loss, adv=adv, fm=fm,
+                        d_x_ts=x_ts.grad, d_fake=fake.grad, wsum=ck)
+            if ms:
+                arrs["s"] = s
+            for i in range(5):
+                arrs["fc%d" % i] = fc[i]
+                arrs["fu%d" % i] = fu[i]
+                arrs["rc%d" % i] = rc[i]
+                arrs["ru%d" % i] = ru[i]
+            for k, p in D.named_parameters():
+                dg, corner = grad_digest(p.grad)
+                arrs["dw_sum/" + k] = dg
+                arrs["dw_corner/" + k] = corner
+            save(name, **arrs)
+
+    # mel L1 (model/loss.py:229-242)
+    print("mel loss")
+    B, L = 3, 21
+    lens = torch.tensor([21, 13, 17])
+    pad = torch.arange(L)[None, :] >= lens[:, None]
+    pred = torch.from_numpy(rng.standard_normal((B, L, M)).astype(np.float32))
+    targ = torch.from_numpy(rng.standard_normal((B, L, M)).astype(np.float32))
+    holder = types.SimpleNamespace(mel_masks_fill=pad)
+    holder.l1_loss = types.MethodType(ref_loss.MixGANTTSLoss.l1_loss, holder)
+    holder.weights_nonzero_speech = types.MethodType(ref_loss.MixGANTTSLoss.weights_nonzero_speech, holder)
+    ml = ref_loss.MixGANTTSLoss.get_mel_loss(holder, pred, targ)
+    save("mel_loss", pred=pred, targ=targ, pad=pad, loss=ml)
+
+    # (ix) FFT block / Decoder / PostNet ---------------------------------------------------------
+    print("fft")
+    blk = FFTBlock(256, 2, 128, 128, 1024, 9, dropout=0.2).eval()
+    ck = seed_module(blk, 51, "fftblock")
+    B, L = 2, 40
+    lens = torch.tensor([40, 29])
+    pad = torch.arange(L)[None, :] >= lens[:, None]
+    x = torch.from_numpy(rng.standard_normal((B, L, 256)).astype(np.float32)).requires_grad_()
+    go = torch.from_numpy(rng.standard_normal((B, L, 256)).astype(np.float32))
+    y, _ = blk(x, mask=pad, slf_attn_mask=pad.unsqueeze(1).expand(-1, L, -1))
+    (y * go).sum().backward()
+    arrs = dict(x=x, pad=pad, go=go, out=y, d_x=x.grad, wsum=ck)
+    for k, p in blk.named_parameters():
+        dg, corner = grad_digest(p.grad)
+        arrs["dw_sum/" + k] = dg
+        arrs["dw_corner/" + k] = corner
+    save("fftblock", **arrs)
+
+    _, pre, mc, _ = configs("shallow", 4, stats_dir=stats, max_seq_len=48)
+    dec = Decoder(mc).eval()
+    ck = seed_module(dec, 52, "decoder")
+    arrs = dict(wsum=ck, max_seq_len=48)
+    for tag, L, lens in (("short", 40, [40, 31]), ("long", 60, [60, 47])):
+        lens = torch.tensor(lens)
+        pad = torch.arange(L)[None, :] >= lens[:, None]
+        x = torch.from_numpy(rng.standard_normal((2, L, 256)).astype(np.float32))
+        with torch.no_grad():
+            y = dec(x, pad)
+        arrs.update({tag + "_x": x, tag + "_pad": pad, tag + "_out": y})
+    save("decoder", **arrs)
+
+    pn = PostNet().eval()
+    ck = seed_module(pn, 53, "postnet")
+    x = torch.from_numpy(rng.standard_normal((2, 40, M)).astype(np.float32))
+    with torch.no_grad():
+        y = pn(x)
+    save("postnet", x=x, out=y, wsum=ck)
+
+    with open(os.path.join(OUT, "manifest.json"), "w") as f:
+        json.dump(MANIFEST, f, indent=0, sort_keys=True)
+    print("manifest written")
+
+
+if __name__ == "__main__":
+    main()
