@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- denoiser steps/sec on the MI355X HIP path (BASELINE.json metric).
+
+A "step" is one reverse-diffusion step on a whole batch: Denoiser.forward + clamp +
+q_posterior_sample (the reference's p_sample, model/diffusion.py:121-129), at BASELINE
+configs[1]: LJSpeech 'naive' model, B=16 per GPU, 80 mel bins, L=1000 frames, fp32.
+Inputs are synthetic and already resident in HBM; weights are seeded random (no checkpoints
+ship with the reference).  N>1: one process per GPU, each with its own batch (weak scaling);
+the path has no data-path collective at inference.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (the dominant
+kernel, the k=3 gated conv, from HIP events recorded on the launch stream inside the timed
+region) and `cpu_baseline` (the CPU oracle timed on this box's host cores, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+B_PER_GPU = 16
+L_FRAMES = 1000
+MEL = 80
+FLOP_PER_FRAME = 23_805_952            # Denoiser.forward per frame
+K3_FLOP_PER_FRAME = 2 * 512 * 768      # the dominant kernel: Conv1d(256->512, k=3) of one layer
+FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=B_PER_GPU)
+    ap.add_argument("--frames", type=int, default=L_FRAMES)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    import mixgan_tts_amd as mg
+    from mixgan_tts_amd import ops, _lib
+    from helpers import hot_path_configs, write_stats
+
+    B, L = args.batch, args.frames
+    with tempfile.TemporaryDirectory() as d:
+        stats = write_stats(d, [-11.5] * MEL, [2.0] * MEL)
+        gd = mg.GaussianDiffusion(*hot_path_configs("naive", 4, stats_dir=stats))
+    # seeded N(0, 1/fan_in) weights incl. a non-zero output projection (the shipped init zeroes it)
+    gen = torch.Generator().manual_seed(1234)
+    with torch.no_grad():
+        for p in gd.denoise_fn.parameters():
+            fan = p[0].numel() if p.dim() > 1 else 1
+            p.copy_(torch.randn(p.shape, generator=gen) * (fan ** -0.5 if p.dim() > 1 else 0.1))
+    gd = gd.to(dev).eval()
+    den = gd.denoise_fn
+    rng = np.random.default_rng(1234 + rank)
+    cond = torch.from_numpy(rng.standard_normal((B, 256, L)).astype(np.float32)).to(dev)
+    x = torch.from_numpy(rng.standard_normal((B, MEL, L)).astype(np.float32)).to(dev)
+    buf = gd._buf()
+    packed = den.packed_weights()
+    T = gd.num_timesteps
+    ts = [torch.full((B,), i, device=dev, dtype=torch.long) for i in range(T)]
+    x0 = torch.empty_like(x)
+    bufs = [torch.empty_like(x), torch.empty_like(x)]
+    noise = torch.empty_like(x)
+
+    def step(i, xin, xout):
+        t = ts[(T - 1 - i) % T]
+        den.run(xin, t, cond, None, out=x0, packed=packed)
+        noise.normal_()
+        ops.posterior_sample(x0, xin, t, noise, None, buf, clip=True, out=xout)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    cur = x
+    for i in range(args.warmup):
+        step(i, cur, bufs[i & 1])
+        cur = bufs[i & 1]
+    n_layers = len(den.residual_layers)
+    Lh = _lib.lib()
+    _lib.check(Lh.mg_profile_begin(args.steps * n_layers))
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, cur, bufs[i & 1])
+        cur = bufs[i & 1]
+    sync()
+    dt = time.perf_counter() - t0
+    ms = (ctypes.c_float * (args.steps * n_layers))()
+    n_ev = Lh.mg_profile_end(ms, args.steps * n_layers)
+    assert torch.isfinite(cur).all(), "non-finite output"
+
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        k_ms = float(np.mean(np.frombuffer(ms, dtype=np.float32)[:n_ev])) if n_ev > 0 else float("nan")
+        k_flop = K3_FLOP_PER_FRAME * B * L
+        achieved = k_flop / (k_ms * 1e-3) / 1e12
+        value = world * args.steps / dt
+        whole = FLOP_PER_FRAME * B * L * args.steps / dt / 1e12
+        line = {
+            "metric": "denoiser steps/sec (80-mel, L=1000 frames, B=16 per GPU)",
+            "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: LJSpeech naive, p_sample step (Denoiser.forward + clamp + "
+                                   "posterior sample), B=%d/GPU, L=%d, 80 mel, T=4 schedule" % (B, L),
+                       "parallelism": "replicas x%d (batch-sharded, no collective)" % world},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel<K=3> 256->512 + GLU gate epilogue",
+                         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel_ms": round(k_ms, 4), "launches_timed": int(n_ev),
+                         "whole_step_tflops": round(whole, 2),
+                         "whole_step_frac": round(whole / FP32_MFMA_PEAK_TFLOPS, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(gd, B, L)
+            line["speedup_vs_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(gd, B, L):
+    """The CPU oracle (oracle/refmath.py, the reference's op sequence incl. torch.stack of the 20
+    skips) on the host cores: the same p_sample step, same B and L, bounded to ~20 s."""
+    from oracle import refmath as R
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    W = {k: v.detach().cpu() for k, v in gd.state_dict().items()}
+    buf = {k: v.detach().cpu() for k, v in gd._buf().items()}
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, 1, MEL, L, generator=g)
+    cond = torch.randn(B, 256, L, generator=g)
+    t = torch.full((B,), 3, dtype=torch.long)
+    times = []
+    t_start = time.perf_counter()
+    for i in range(12):
+        nz = torch.randn(B, 1, MEL, L, generator=g)
+        t0 = time.perf_counter()
+        R.p_sample(W, buf, x, t, cond, None, nz)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > 20 and len(times) >= 3:
+            break
+    med = float(np.median(times[1:])) if len(times) > 1 else times[0]
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except Exception:
+        pass
+    return {"value": round(1.0 / med, 4), "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": "%d timed p_sample steps (median, 1 warm-up dropped) at the same B=%d, L=%d on %s"
+                      % (max(1, len(times) - 1), B, L, model)}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,158 @@
+/*
+ * mixgan_hip.h -- C ABI of libmixgan_hip.so: the MI355X (gfx950) implementation of the
+ * MixGAN-TTS diffusion hot path.
+ *
+ * The reference has no FFI for this path: its boundary is the Python nn.Module surface
+ * (SURVEY.md section 8b).  Each entry point below names the reference function it stands in
+ * for (file:line relative to the reference tree); the host-side mirror classes under
+ * mixgan-tts_amd/ keep the reference's names, signatures and state_dict keys and call these
+ * through ctypes.  INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - all tensors are dense fp32 (timesteps int64), caller-owned device memory;
+ *   - the library never allocates device memory, never synchronises the host and enqueues
+ *     only on `stream` (a hipStream_t passed as void*), so every call is hipGraph-capturable;
+ *   - return 0 on success, <0 for argument/shape errors (MG_ERR_*), >0 = hipError_t;
+ *   - sequence tensors are channel-major [B, C, L] (frames contiguous) unless stated.
+ */
+#ifndef MIXGAN_HIP_H
+#define MIXGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MG_OK 0
+#define MG_ERR_ARG (-1)       /* null pointer / bad enum */
+#define MG_ERR_SHAPE (-2)     /* dimension the kernels do not support */
+#define MG_ERR_WORKSPACE (-3) /* workspace too small */
+
+#define MG_VERSION 100
+
+int mg_version(void);
+/* Human-readable text for a return code (negative: ours; positive: hipGetErrorString). */
+const char *mg_error_string(int code);
+
+/* ------------------------------------------------------------------ activations */
+#define MG_ACT_NONE 0
+#define MG_ACT_RELU 1
+#define MG_ACT_LRELU02 2 /* F.leaky_relu(x, 0.2): model/mixgantts.py:273,282,286 */
+#define MG_ACT_TANH 3
+
+/* ------------------------------------------------------------------ Conv1d / Linear as MFMA GEMM
+ * Stands in for every nn.Conv1d / nn.Linear on the path (ConvNorm model/blocks.py:364-371,
+ * LinearNorm model/blocks.py:289-291, transformer/SubLayers.py:67-80, transformer/Layers.py:67-137).
+ *
+ * Weights are consumed in a packed, MFMA-fragment-ordered layout that is a *derived cache* of
+ * the stored [Co, Ci, K] parameter (checkpoints keep the reference layout).
+ */
+#define MG_PACK_PLAIN 0  /* rows in natural order */
+#define MG_PACK_GATE 1   /* rows interleaved so that channel c and c+Co/2 share a lane (GLU gate) */
+#define MG_PACK_DGRAD 2  /* transposed + tap-flipped: the data-gradient convolution (stride 1) */
+
+/* Number of floats of the packed form of a [Co, Ci, K] weight. */
+size_t mg_conv_packed_floats(int Co, int Ci, int K, int mode);
+/* w: [Co, Ci, K] fp32 -> packed. */
+int mg_conv_pack(const float *w, float *packed, int Co, int Ci, int K, int mode, void *stream);
+
+/* out[b, co, l] = act(alpha * sum_{ci,k} w[co,ci,k] * (in[b, ci, l*stride + k - pad] + in_vec[b,ci])
+ *                     + bias[co]) (+ add[b,co,l]) (+ out_old if accumulate)
+ * in: [B, Ci, Lin]; out/add: [B, Co, Lout]; bias may be NULL; in_vec ([B, Ci], added to in-range
+ * input positions only, i.e. before zero padding) may be NULL.  K in {1,3,5,9}, stride in {1,2}. */
+int mg_conv1d_fwd(const float *in, const float *in_vec, const float *packed, const float *bias,
+                  const float *add, float *out, int B, int Ci, int Lin, int Co, int Lout, int K,
+                  int stride, int pad, int act, float alpha, int accumulate, void *stream);
+
+/* ------------------------------------------------------------------ diffusion algebra (HBM-bound)
+ * Schedule tables are the fp32 buffers of GaussianDiffusion (model/diffusion.py:60-83). */
+
+/* diffuse_fn + q_sample (model/diffusion.py:177-185, 147-153), fused with norm_spec (:228),
+ * the [B,L,M] -> [B,1,M,L] transpose and the mask multiply of :206-207.
+ *   mel [B, L, M]; t int64 [B] (t<0 rows return the clean normalised mel); noise [B, M, L];
+ *   keep uint8 [B, L] (1 = valid frame) or NULL; out [B, M, L].                                   */
+int mg_diffuse_fwd(const float *mel, const int64_t *t, const float *noise, const uint8_t *keep,
+                   const float *spec_min, const float *spec_max, const float *sqrt_ac,
+                   const float *sqrt_1mac, float *out, int B, int L, int M, int T, void *stream);
+
+/* q_posterior_sample (model/diffusion.py:104-119) with the clamp_ of :126-127 / :211-212 and the
+ * mask multiply of :220 fused:  x0c = clamp(x0 (* keep), -1, 1) if clip;
+ *   out = (coef1[t] x0c + coef2[t] x_t + [t != 0] exp(0.5 logvar[t]) noise) (* keep).
+ * If x0_clamped_out != NULL the masked+clamped x0 is written there (training returns it).
+ * Tensors [B, M, L]; keep uint8 [B, L] or NULL (p_sample applies no mask). */
+int mg_posterior_sample_fwd(const float *x0, const float *x_t, const int64_t *t, const float *noise,
+                            const uint8_t *keep, const float *coef1, const float *coef2,
+                            const float *logvar, float *out, float *x0_clamped_out, int clip, int B,
+                            int L, int M, int T, void *stream);
+
+/* Gradient of mg_posterior_sample_fwd w.r.t. x0 (everything else on the path is data):
+ *   g_x0 = keep * 1[-1 <= x0*keep <= 1 or !clip] * (g_x0c + coef1[t] * keep * g_xpp).
+ * g_x0c or g_xpp may be NULL (not both). */
+int mg_posterior_sample_bwd(const float *x0, const int64_t *t, const uint8_t *keep,
+                            const float *coef1, const float *g_x0c, const float *g_xpp, float *g_x0,
+                            int clip, int B, int L, int M, int T, void *stream);
+
+/* norm_spec / denorm_spec (model/diffusion.py:228-232) on a flat [n/M, M] tensor:
+ * mode 1 norm, 2 denorm, 3 gradient of norm (g * 2/(max-min)), 4 gradient of denorm. */
+int mg_spec_affine(const float *in, float *out, const float *spec_min, const float *spec_max,
+                   int mode, size_t n, int M, void *stream);
+
+/* [B, M, L] <-> [B, L, M] transposes with optional norm/denorm_spec (model/diffusion.py:228-232):
+ * mode 0 plain, 1 norm_spec on the way in (BLM->BML), 2 denorm_spec on the way out (BML->BLM). */
+int mg_transpose_bml(const float *in, float *out, const float *spec_min, const float *spec_max,
+                     const uint8_t *keep, int to_blm, int mode, int B, int L, int M, void *stream);
+
+/* ------------------------------------------------------------------ Denoiser (model/modules.py:382-446)
+ * Weight pointer table order for mg_denoiser_pack (names are the reference state_dict keys under
+ * `diffusion.denoise_fn.`):
+ *   [0] input_projection.0.conv.weight [C,M,1]   [1] input_projection.0.conv.bias [C]
+ *   [2] mlp.0.linear.weight [4C,C]               [3] mlp.2.linear.weight [C,4C]
+ *   [4] skip_projection.conv.weight [C,C,1]      [5] skip_projection.conv.bias [C]
+ *   [6] output_projection.conv.weight [M,C,1]    [7] output_projection.conv.bias [M]
+ *   then per residual layer i (8 + 9*i + j):
+ *   j=0 conv_layer.conv.weight [2C,C,3]          j=1 conv_layer.conv.bias [2C]
+ *   j=2 diffusion_projection.linear.weight [C,C] j=3 conditioner_projection.conv.weight [C,H,1]
+ *   j=4 conditioner_projection.conv.bias [C]     j=5 output_projection.conv.weight [2C,C,1]
+ *   j=6 output_projection.conv.bias [2C]         j=7 speaker_projection.linear.weight [C,H] or NULL
+ *   j=8 reserved (NULL)
+ */
+typedef struct {
+    int32_t n_layers;      /* model.denoiser.residual_layers (20) */
+    int32_t channels;      /* C: residual_channels (256)          */
+    int32_t cond_channels; /* H: transformer.encoder_hidden (256) */
+    int32_t mel_bins;      /* M: n_mel_channels (80)              */
+    int32_t multi_speaker; /* 0/1                                 */
+} mg_denoiser_dims;
+
+#define MG_DEN_HEAD_PTRS 8
+#define MG_DEN_LAYER_PTRS 9
+
+size_t mg_denoiser_packed_floats(const mg_denoiser_dims *d);
+/* freq: the C/2 step-embedding frequencies exp(-i ln(1e4)/(C/2-1)) (model/blocks.py:909-910),
+ * computed by the host exactly as the reference does and cached in the packed blob. */
+int mg_denoiser_pack(const mg_denoiser_dims *d, const float *const *weights, const float *freq,
+                     float *packed, void *stream);
+/* Workspace (floats) for a forward of batch B, L frames.  save_for_backward additionally keeps the
+ * per-layer activations that mg_denoiser_bwd consumes. */
+size_t mg_denoiser_workspace_floats(const mg_denoiser_dims *d, int B, int L, int save_for_backward);
+
+/* Denoiser.forward: x_t [B, M, L] (the reference's [B,1,M,L]), t int64 [B], cond [B, H, L],
+ * spk [B, H] or NULL -> out [B, M, L].  */
+int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, const float *x_t,
+                    const int64_t *t, const float *cond, const float *spk, float *out,
+                    float *workspace, size_t workspace_floats, int B, int L, int save_for_backward,
+                    void *stream);
+
+/* ------------------------------------------------------------------ measurement hooks (bench.py)
+ * While a session is open, mg_denoiser_fwd brackets each launch of its dominant kernel (the k=3
+ * gated convolution of a residual layer) with HIP events recorded on the launch stream.
+ * mg_profile_end waits for them and returns the number of brackets written to ms_out. */
+int mg_profile_begin(int max_brackets);
+int mg_profile_end(float *ms_out, int max_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIXGAN_HIP_H */

@@ -1,0 +1,113 @@
+"""ctypes binding of libmixgan_hip.so (C ABI: include/mixgan_hip.h)."""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+EXPORTS = (
+    "mg_version", "mg_error_string",
+    "mg_conv_packed_floats", "mg_conv_pack", "mg_conv1d_fwd",
+    "mg_diffuse_fwd", "mg_posterior_sample_fwd", "mg_posterior_sample_bwd", "mg_spec_affine", "mg_transpose_bml",
+    "mg_denoiser_packed_floats", "mg_denoiser_pack", "mg_denoiser_workspace_floats", "mg_denoiser_fwd",
+    "mg_profile_begin", "mg_profile_end",
+)
+
+
+class MixganHipError(RuntimeError):
+    pass
+
+
+class DenoiserDims(ctypes.Structure):
+    _fields_ = [("n_layers", ctypes.c_int32), ("channels", ctypes.c_int32), ("cond_channels", ctypes.c_int32),
+                ("mel_bins", ctypes.c_int32), ("multi_speaker", ctypes.c_int32)]
+
+
+def library_path():
+    return os.path.join(_HERE, "libmixgan_hip.so")
+
+
+def build(force=False):
+    """Compile the HIP sources in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force or not os.path.exists(library_path()):
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j4"] + (["-B"] if force else []))
+    return library_path()
+
+
+def lib():
+    """Load the HIP library; raises (never falls back) when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise MixganHipError(
+                "libmixgan_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C mixgan-tts_amd/csrc`. There is no CPU fallback." % path)
+        L = ctypes.CDLL(path)
+        L.mg_error_string.restype = ctypes.c_char_p
+        _declare(L)
+        _LIB = L
+    return _LIB
+
+
+def _declare(L):
+    """argtypes/restype for every export of include/mixgan_hip.h."""
+    vp, i, f, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+    dp = ctypes.POINTER(DenoiserDims)
+    sig = {
+        "mg_version": (i, []),
+        "mg_error_string": (ctypes.c_char_p, [i]),
+        "mg_conv_packed_floats": (sz, [i, i, i, i]),
+        "mg_conv_pack": (i, [vp, vp, i, i, i, i, vp]),
+        "mg_conv1d_fwd": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, f, i, vp]),
+        "mg_diffuse_fwd": (i, [vp] * 9 + [i, i, i, i, vp]),
+        "mg_posterior_sample_fwd": (i, [vp] * 10 + [i, i, i, i, i, vp]),
+        "mg_transpose_bml": (i, [vp] * 5 + [i, i, i, i, i, vp]),
+        "mg_posterior_sample_bwd": (i, [vp] * 7 + [i, i, i, i, i, vp]),
+        "mg_spec_affine": (i, [vp, vp, vp, vp, i, sz, i, vp]),
+        "mg_denoiser_packed_floats": (sz, [dp]),
+        "mg_denoiser_pack": (i, [dp, vp, vp, vp, vp]),
+        "mg_denoiser_workspace_floats": (sz, [dp, i, i, i]),
+        "mg_denoiser_fwd": (i, [dp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, vp]),
+        "mg_profile_begin": (i, [i]),
+        "mg_profile_end": (i, [vp, i]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+
+
+def check(rc):
+    if rc != 0:
+        raise MixganHipError("libmixgan_hip: %s (code %d)" % (lib().mg_error_string(rc).decode(), rc))
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def fptr(t, allow_none=False):
+    """Device pointer of a contiguous fp32 CUDA tensor (the ABI takes plain pointers)."""
+    if t is None:
+        if allow_none:
+            return ctypes.c_void_p(0)
+        raise MixganHipError("missing tensor")
+    if not t.is_cuda:
+        raise MixganHipError("tensor is not on the GPU: the HIP path has no CPU fallback")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise MixganHipError("expected a contiguous fp32 tensor, got %s contiguous=%s" % (t.dtype, t.is_contiguous()))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def iptr(t, dtype, allow_none=False):
+    if t is None:
+        if allow_none:
+            return ctypes.c_void_p(0)
+        raise MixganHipError("missing tensor")
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise MixganHipError("expected a contiguous %s CUDA tensor" % dtype)
+    return ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,258 @@
+// Conv1d / Linear as an implicit GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32), gfx950.
+//
+// Data layout.  Activations are channel-major [B, C, L] with the frame axis contiguous -- the
+// reference's own Conv1d layout -- so a [CK channels x TW frames] slab of the input is a set of
+// contiguous row segments: coalesced HBM reads straight into an LDS tile, halo included.  With
+// the GEMM written as   out[co, l] = sum_{(tap,ci)} W[co, (tap,ci)] * in[ci, l*stride + tap - pad]
+// the MFMA B operand of k-step (ci, ci+1) is "32 consecutive frames of row ci / ci+1" of that
+// LDS tile: one conflict-free ds_read_b32 per MFMA, no im2col, and the tap shift is an address
+// offset.  The A operand (weights) is pre-packed in MFMA fragment order and streamed global/L2 ->
+// VGPR as one float4 per lane per 4 k-steps (1 KiB per wave-instruction); every workgroup reads
+// the same few MB of weights, which stay resident in each XCD's 4 MiB L2.
+//
+// Tiling.  Workgroup = 256 threads = 4 waves as 2(M) x 2(N); wave tile (32*WM) x 64, i.e.
+// WM x 2 accumulator tiles of 32x32 (f32x16 each).  Workgroup tile MT = 64*WM output channels x
+// NT = 128 output frames of one batch element.  K loop: chunks of CK input channels staged in a
+// double-buffered LDS tile (register-staged prefetch of chunk c+1 behind the MFMAs of chunk c,
+// one barrier per chunk).
+//
+// Packed weight layout (mg_conv_pack):  Wp[mb][q][lane][e], mb = 32-row block of M, q = k-group
+// counter in loop order (chunk, tap, 8-channel group), lane 0..63, e 0..3:
+//     ci  = chunk*CK + g*8 + 2*e + (lane >> 5),   row = rowmap(mb, lane & 31)
+// so element e of the float4 is the A fragment (A[i = lane&31][k = lane>>5]) of k-step e.
+#pragma once
+#include "common.h"
+
+#define MG_NT 128
+
+struct ConvArgs {
+    const float *in;      // [B, Ci, Lin]
+    const float *in_vec;  // optional [B, Ci]: added to in-range input samples
+    const float *wp;      // packed weights
+    long in_bs;           // batch stride of `in` (floats)
+    int in_rs;            // row (channel) stride of `in` (floats), normally Lin
+    int B, Ci, CiP, Lin, Lout, pad;
+    int ntiles_per_b, ntiles_total;
+};
+
+// number of k-groups (8 channels x 1 tap) per 32-row block
+static inline int mg_conv_qcount(int CiP, int K) { return CiP * K / 8; }
+static inline int mg_conv_ck(int K) { return K <= 3 ? 32 : 16; }
+static inline int mg_round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// ---------------------------------------------------------------------------------------------
+// Epilogues.  acc[i][j][r] of the wave at (mrow0, l0w) is the output element
+//     row = mrow0 + i*32 + 8*(r>>2) + 4*(lane>>5) + (r&3),   frame = l0w + j*32 + (lane&31).
+// ---------------------------------------------------------------------------------------------
+struct EpiBiasAct {
+    struct Params {
+        float *out;        // [B, Co, Lout]
+        const float *bias; // [Co] or null
+        const float *add;  // [B, Co, Lout] or null
+        float alpha;
+        int Co;
+        int act;           // MG_ACT_*
+        int accumulate;    // out += result
+    };
+    template <int WM>
+    static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][2], int b, int mrow0, int l0w,
+                                               int lane, int Lout)
+    {
+        const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mrow0 + i * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                if (row >= p.Co) continue;
+                const float bv = p.bias ? p.bias[row] : 0.f;
+                float *orow = p.out + ((size_t)b * p.Co + row) * Lout;
+                const float *arow = p.add ? p.add + ((size_t)b * p.Co + row) * Lout : nullptr;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int l = l0w + j * 32 + c;
+                    if (l < Lout) {
+                        float v = acc[i][j][r] * p.alpha + bv;
+                        switch (p.act) {
+                        case MG_ACT_RELU: v = mg_act<MG_ACT_RELU>(v); break;
+                        case MG_ACT_LRELU02: v = mg_act<MG_ACT_LRELU02>(v); break;
+                        case MG_ACT_TANH: v = mg_act<MG_ACT_TANH>(v); break;
+                        default: break;
+                        }
+                        if (arow) v += arow[l];
+                        if (p.accumulate) v += orow[l];
+                        orow[l] = v;
+                    }
+                }
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+template <int KW, int STRIDE, int CK, int WM, class Epi>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, typename Epi::Params ep)
+{
+    constexpr int NT = MG_NT;
+    constexpr int TW = NT * STRIDE + KW - 1;  // input frames per tile row (>= (NT-1)*STRIDE + KW)
+    constexpr int TILE = CK * TW;
+    constexpr int NLD = (TILE + 255) / 256;
+    constexpr int QC = KW * (CK / 8);  // k-groups per chunk
+
+    __shared__ float lds[2][TILE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, c32 = lane & 31;
+
+    const int nt = blockIdx.x % a.ntiles_total;
+    const int mt = blockIdx.x / a.ntiles_total;
+    const int b = nt / a.ntiles_per_b;
+    const int l0 = (nt % a.ntiles_per_b) * NT;
+    const int mb0 = mt * (2 * WM) + wm * WM;  // first 32-row block of this wave
+
+    const int nchunks = a.CiP / CK;
+    const int Q = nchunks * QC;
+
+    // A (weight) stream: one float4 per lane per k-group, sequential in q.
+    const f32x4 *ap[WM];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) ap[i] = reinterpret_cast<const f32x4 *>(a.wp) + ((size_t)(mb0 + i) * Q) * 64 + lane;
+
+    f32x16 acc[WM][2];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const float *inb = a.in + (size_t)b * a.in_bs;
+    const int lbase = l0 * STRIDE - a.pad;
+
+    float stage[NLD];
+    auto load_stage = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + k * 256;
+            const int row = idx / TW;
+            const int col = idx - row * TW;
+            const int ci = chunk * CK + row;
+            const int l = lbase + col;
+            float v = 0.f;
+            if (idx < TILE && ci < a.Ci && l >= 0 && l < a.Lin) {
+                v = inb[(size_t)ci * a.in_rs + l];
+                if (a.in_vec) v += a.in_vec[(size_t)b * a.Ci + ci];
+            }
+            stage[k] = v;
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + k * 256;
+            if (idx < TILE) lds[buf][idx] = stage[k];
+        }
+    };
+
+    f32x4 a_cur[WM], a_nxt[WM];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) a_cur[i] = ap[i][0];
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+
+    int q = 0;
+    const int boff = (wn * 64 + c32) * STRIDE + h * TW;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (ch + 1 < nchunks) load_stage(ch + 1);
+        const float *L = lds[ch & 1];
+#pragma unroll
+        for (int tap = 0; tap < KW; ++tap) {
+#pragma unroll
+            for (int g = 0; g < CK / 8; ++g) {
+                ++q;
+                const int qn = q < Q ? q : Q - 1;
+#pragma unroll
+                for (int i = 0; i < WM; ++i) a_nxt[i] = ap[i][(size_t)qn * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int s = g * 4 + e;
+                    const float b0 = L[boff + (2 * s) * TW + tap];
+                    const float b1 = L[boff + (2 * s) * TW + tap + 32 * STRIDE];
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) {
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][e], b0, acc[i][0], 0, 0, 0);
+                        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][e], b1, acc[i][1], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < WM; ++i) a_cur[i] = a_nxt[i];
+            }
+        }
+        if (ch + 1 < nchunks) store_stage((ch + 1) & 1);
+        __syncthreads();
+    }
+
+    Epi::template run<WM>(ep, acc, b, (mt * 2 + wm) * (32 * WM), l0 + wn * 64, lane, a.Lout);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-side launcher.  Mrows = number of GEMM rows in the packed weight (before any pairing).
+// ---------------------------------------------------------------------------------------------
+struct ConvShape {
+    int B, Ci, Lin, Lout, K, stride, pad, Mrows;
+    long in_bs;  // 0 -> Ci*Lin
+    int in_rs;   // 0 -> Lin
+};
+
+template <int KW, int STRIDE, int CK, int WM, class Epi>
+static int conv_launch_t(const ConvShape &s, const float *in, const float *in_vec, const float *wp,
+                         const typename Epi::Params &ep, hipStream_t st)
+{
+    ConvArgs a;
+    a.in = in;
+    a.in_vec = in_vec;
+    a.wp = wp;
+    a.in_bs = s.in_bs ? s.in_bs : (long)s.Ci * s.Lin;
+    a.in_rs = s.in_rs ? s.in_rs : s.Lin;
+    a.B = s.B;
+    a.Ci = s.Ci;
+    a.CiP = mg_round_up(s.Ci, CK);
+    a.Lin = s.Lin;
+    a.Lout = s.Lout;
+    a.pad = s.pad;
+    a.ntiles_per_b = mg_cdiv(s.Lout, MG_NT);
+    a.ntiles_total = a.ntiles_per_b * s.B;
+    const int mtiles = mg_cdiv(s.Mrows, 64 * WM);
+    dim3 grid((unsigned)(a.ntiles_total * mtiles));
+    hipLaunchKernelGGL((conv_mfma_kernel<KW, STRIDE, CK, WM, Epi>), grid, dim3(256), 0, st, a, ep);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
+}
+
+// Dispatch on (K, stride); CK must match mg_conv_ck().  WM = 2 (MT = 128) when Mrows > 64.
+template <class Epi>
+static int conv_launch(const ConvShape &s, const float *in, const float *in_vec, const float *wp,
+                       const typename Epi::Params &ep, hipStream_t st)
+{
+    if (s.B <= 0 || s.Lout <= 0 || s.Ci <= 0 || s.Mrows <= 0) return MG_ERR_SHAPE;
+    const bool big = s.Mrows > 64;
+#define MG_CONV_CASE(KW_, ST_, CK_)                                                              \
+    if (s.K == KW_ && s.stride == ST_)                                                           \
+        return big ? conv_launch_t<KW_, ST_, CK_, 2, Epi>(s, in, in_vec, wp, ep, st)            \
+                   : conv_launch_t<KW_, ST_, CK_, 1, Epi>(s, in, in_vec, wp, ep, st);
+    MG_CONV_CASE(1, 1, 32)
+    MG_CONV_CASE(3, 1, 32)
+    MG_CONV_CASE(5, 1, 16)
+    MG_CONV_CASE(9, 1, 16)
+    MG_CONV_CASE(5, 2, 16)
+#undef MG_CONV_CASE
+    return MG_ERR_SHAPE;
+}
+
+// number of 32-row blocks the packed form holds (padded to the workgroup M tile)
+static inline int mg_conv_mblocks(int Mrows) { return Mrows > 64 ? mg_round_up(Mrows, 128) / 32 : 2; }

@@ -1,0 +1,453 @@
+// Denoiser.forward (model/modules.py:420-446) on gfx950: step-embedding MLP + 20 gated residual
+// blocks (model/blocks.py:1157-1176) + skip/output projections, as fp32-MFMA implicit GEMMs with
+// every elementwise op fused into a GEMM epilogue.
+//
+// Per residual layer (3 launches, all on conv_mfma_kernel):
+//   (1) h = Wc * cond + bc + x + (Wd s [+ Wp spk])            k=1,  EpiCond
+//   (2) g = sigmoid(z[:C]) * tanh(z[C:]),  z = W3 (*) h + b3   k=3,  EpiGate   (rows gate-interleaved)
+//   (3) o = Wo g + bo;  x <- (o[:C] + x + Wd s)/sqrt2;  skip += o[C:]     k=1, EpiResSkip
+// The 20 skip tensors are never materialised (the reference stacks them, model/modules.py:441);
+// a running fp32 sum is kept instead.
+#include "conv_mfma.h"
+
+// ------------------------------------------------------------------------------------------ epilogues
+struct EpiCond {
+    struct Params {
+        float *out;         // h [B, C, L]
+        const float *bias;  // [C]
+        const float *x;     // [B, C, L]
+        const float *vec;   // [B, C]  (Wd s [+ Wp spk])
+        int C;
+    };
+    template <int WM>
+    static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][2], int b, int mrow0, int l0w,
+                                               int lane, int Lout)
+    {
+        const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mrow0 + i * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                if (row >= p.C) continue;
+                const float add = p.bias[row] + p.vec[(size_t)b * p.C + row];
+                const size_t ro = ((size_t)b * p.C + row) * Lout;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int l = l0w + j * 32 + c;
+                    if (l < Lout) p.out[ro + l] = acc[i][j][r] + add + p.x[ro + l];
+                }
+            }
+        }
+    }
+};
+
+struct EpiGate {
+    struct Params {
+        float *out;         // g [B, C, L]
+        const float *bias;  // [2C]: gate rows then filter rows (reference order, model/blocks.py:1170)
+        float *sig;         // optional saves for backward: sigmoid(gate), tanh(filter)  [B, C, L]
+        float *tnh;
+        int C;
+    };
+    template <int WM>
+    static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][2], int b, int mrow0, int l0w,
+                                               int lane, int Lout)
+    {
+        // needs the gate/filter 32-row block pair in one wave: only the WM == 2 tiling is launched
+        if constexpr (WM != 2) return;
+        const int h = lane >> 5, c = lane & 31;
+        const int ch0 = (mrow0 / 64) * 32;  // packed block pair -> first output channel
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = ch0 + 8 * (r >> 2) + 4 * h + (r & 3);
+            if (ch >= p.C) continue;
+            const float bg = p.bias[ch], bf = p.bias[p.C + ch];
+            const size_t ro = ((size_t)b * p.C + ch) * Lout;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int l = l0w + j * 32 + c;
+                if (l < Lout) {
+                    const float s = mg_sigmoid(acc[0][j][r] + bg);
+                    const float t = mg_tanh(acc[WM - 1][j][r] + bf);
+                    p.out[ro + l] = s * t;
+                    if (p.sig) {
+                        p.sig[ro + l] = s;
+                        p.tnh[ro + l] = t;
+                    }
+                }
+            }
+        }
+    }
+};
+
+struct EpiResSkip {
+    struct Params {
+        float *x;           // [B, C, L] in/out
+        float *skip;        // [B, C, L] running sum
+        const float *bias;  // [2C]
+        const float *dvec;  // [B, C]  Wd s
+        int C;
+        int first;          // layer 0: skip = ..., else skip += ...
+    };
+    template <int WM>
+    static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][2], int b, int mrow0, int l0w,
+                                               int lane, int Lout)
+    {
+        const int h = lane >> 5, c = lane & 31;
+        const float rs2 = 0.70710678118654752440f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mrow0 + i * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                if (row >= 2 * p.C) continue;
+                const float bv = p.bias[row];
+                if (row < p.C) {
+                    const float dv = p.dvec[(size_t)b * p.C + row];
+                    const size_t ro = ((size_t)b * p.C + row) * Lout;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int l = l0w + j * 32 + c;
+                        if (l < Lout) p.x[ro + l] = (acc[i][j][r] + bv + (p.x[ro + l] + dv)) * rs2;
+                    }
+                } else {
+                    const size_t ro = ((size_t)b * p.C + (row - p.C)) * Lout;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int l = l0w + j * 32 + c;
+                        if (l < Lout) {
+                            const float v = acc[i][j][r] + bv;
+                            p.skip[ro + l] = p.first ? v : p.skip[ro + l] + v;
+                        }
+                    }
+                }
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------ small linears
+// step embedding (model/blocks.py:906-913): emb[b] = [sin(t f_i) | cos(t f_i)], f from the host table
+__global__ void step_embed_kernel(const int64_t *__restrict__ t, const float *__restrict__ freq,
+                                  float *__restrict__ emb, int B, int C)
+{
+    const int half = C / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * half) return;
+    const int b = idx / half, i = idx - b * half;
+    const float ang = (float)t[b] * freq[i];
+    emb[(size_t)b * C + i] = sinf(ang);
+    emb[(size_t)b * C + half + i] = cosf(ang);
+}
+
+// out[z][b][j] = act(sum_i W[z][j][i] * in[b][i]) (+ add[z][b][j]);  one wave per output row j.
+template <int BC>
+__global__ __launch_bounds__(256) void small_linear_kernel(const float *__restrict__ W, long w_zs,
+                                                           const float *__restrict__ in, float *__restrict__ out,
+                                                           long out_zs, const float *__restrict__ add, long add_zs,
+                                                           int B, int N, int K, int mish)
+{
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b0 = blockIdx.y * BC;
+    const int z = blockIdx.z;
+    if (j >= N) return;
+    const float *w = W + (size_t)z * w_zs + (size_t)j * K;
+    float acc[BC];
+#pragma unroll
+    for (int b = 0; b < BC; ++b) acc[b] = 0.f;
+    for (int i = lane; i < K; i += 64) {
+        const float wv = w[i];
+#pragma unroll
+        for (int b = 0; b < BC; ++b)
+            if (b0 + b < B) acc[b] = fmaf(wv, in[(size_t)(b0 + b) * K + i], acc[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < BC; ++b) {
+        float v = acc[b];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0 && b0 + b < B) {
+            if (mish) {  // x * tanh(softplus(x)), softplus threshold 20 (F.softplus defaults)
+                const float sp = v > 20.f ? v : log1pf(expf(v));
+                v = v * tanhf(sp);
+            }
+            const size_t o = (size_t)z * out_zs + (size_t)(b0 + b) * N + j;
+            if (add) v += add[(size_t)z * add_zs + (size_t)(b0 + b) * N + j];
+            out[o] = v;
+        }
+    }
+}
+
+static int small_linear(const float *W, long w_zs, const float *in, float *out, long out_zs, const float *add,
+                        long add_zs, int B, int N, int K, int Z, int mish, hipStream_t st)
+{
+    constexpr int BC = 8;
+    dim3 grid(mg_cdiv(N, 4), mg_cdiv(B, BC), Z);
+    hipLaunchKernelGGL(small_linear_kernel<BC>, grid, dim3(256), 0, st, W, w_zs, in, out, out_zs, add, add_zs, B, N, K,
+                       mish);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
+}
+
+// ------------------------------------------------------------------------------------------ packed blob
+struct DenLayout {
+    // offsets in floats into the packed blob
+    size_t freq, in_w, in_b, mlp0, mlp2, skip_w, skip_b, out_w, out_b, layers, layer_stride;
+    size_t l_w3, l_b3, l_wd, l_wc, l_bc, l_wo, l_bo, l_wp;  // offsets inside a layer record
+    size_t total;
+};
+
+static DenLayout den_layout(const mg_denoiser_dims *d)
+{
+    const int C = d->channels, H = d->cond_channels, M = d->mel_bins;
+    DenLayout o;
+    size_t p = 0;
+    auto take = [&](size_t n) {
+        size_t at = p;
+        p += mg_align_up(n, 64);
+        return at;
+    };
+    o.freq = take(C / 2);
+    o.in_w = take(mg_conv_packed_floats(C, M, 1, MG_PACK_PLAIN));
+    o.in_b = take(C);
+    o.mlp0 = take((size_t)4 * C * C);
+    o.mlp2 = take((size_t)4 * C * C);
+    o.skip_w = take(mg_conv_packed_floats(C, C, 1, MG_PACK_PLAIN));
+    o.skip_b = take(C);
+    o.out_w = take(mg_conv_packed_floats(M, C, 1, MG_PACK_PLAIN));
+    o.out_b = take(M);
+    o.layers = p;
+    size_t q = 0;
+    auto ltake = [&](size_t n) {
+        size_t at = q;
+        q += mg_align_up(n, 64);
+        return at;
+    };
+    o.l_w3 = ltake(mg_conv_packed_floats(2 * C, C, 3, MG_PACK_GATE));
+    o.l_b3 = ltake(2 * C);
+    o.l_wd = ltake((size_t)C * C);
+    o.l_wc = ltake(mg_conv_packed_floats(C, H, 1, MG_PACK_PLAIN));
+    o.l_bc = ltake(C);
+    o.l_wo = ltake(mg_conv_packed_floats(2 * C, C, 1, MG_PACK_PLAIN));
+    o.l_bo = ltake(2 * C);
+    o.l_wp = ltake(d->multi_speaker ? (size_t)C * H : 0);
+    o.layer_stride = q;
+    o.total = p + q * d->n_layers;
+    return o;
+}
+
+static int den_check(const mg_denoiser_dims *d)
+{
+    if (!d) return MG_ERR_ARG;
+    if (d->n_layers <= 0 || d->n_layers > 256 || d->channels <= 0 || d->channels % 64 || d->cond_channels <= 0 ||
+        d->mel_bins <= 0)
+        return MG_ERR_SHAPE;
+    return MG_OK;
+}
+
+extern "C" size_t mg_denoiser_packed_floats(const mg_denoiser_dims *d)
+{
+    if (den_check(d) != MG_OK) return 0;
+    return den_layout(d).total;
+}
+
+static int copy_d2d(float *dst, const float *src, size_t n, hipStream_t st)
+{
+    if (!src) return MG_ERR_ARG;
+    hipError_t e = hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+    return e == hipSuccess ? MG_OK : (int)e;
+}
+
+extern "C" int mg_denoiser_pack(const mg_denoiser_dims *d, const float *const *w, const float *freq, float *packed,
+                                void *stream)
+{
+    MG_TRY(den_check(d));
+    if (!w || !packed || !freq) return MG_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int C = d->channels, H = d->cond_channels, M = d->mel_bins;
+    const DenLayout o = den_layout(d);
+    for (int i = 0; i < MG_DEN_HEAD_PTRS; ++i)
+        if (!w[i]) return MG_ERR_ARG;
+    MG_TRY(copy_d2d(packed + o.freq, freq, C / 2, st));
+    MG_TRY(mg_conv_pack(w[0], packed + o.in_w, C, M, 1, MG_PACK_PLAIN, stream));
+    MG_TRY(copy_d2d(packed + o.in_b, w[1], C, st));
+    MG_TRY(copy_d2d(packed + o.mlp0, w[2], (size_t)4 * C * C, st));
+    MG_TRY(copy_d2d(packed + o.mlp2, w[3], (size_t)4 * C * C, st));
+    MG_TRY(mg_conv_pack(w[4], packed + o.skip_w, C, C, 1, MG_PACK_PLAIN, stream));
+    MG_TRY(copy_d2d(packed + o.skip_b, w[5], C, st));
+    MG_TRY(mg_conv_pack(w[6], packed + o.out_w, M, C, 1, MG_PACK_PLAIN, stream));
+    MG_TRY(copy_d2d(packed + o.out_b, w[7], M, st));
+    for (int l = 0; l < d->n_layers; ++l) {
+        const float *const *lw = w + MG_DEN_HEAD_PTRS + (size_t)l * MG_DEN_LAYER_PTRS;
+        float *lp = packed + o.layers + (size_t)l * o.layer_stride;
+        for (int j = 0; j < 7; ++j)
+            if (!lw[j]) return MG_ERR_ARG;
+        MG_TRY(mg_conv_pack(lw[0], lp + o.l_w3, 2 * C, C, 3, MG_PACK_GATE, stream));
+        MG_TRY(copy_d2d(lp + o.l_b3, lw[1], 2 * C, st));
+        MG_TRY(copy_d2d(lp + o.l_wd, lw[2], (size_t)C * C, st));
+        MG_TRY(mg_conv_pack(lw[3], lp + o.l_wc, C, H, 1, MG_PACK_PLAIN, stream));
+        MG_TRY(copy_d2d(lp + o.l_bc, lw[4], C, st));
+        MG_TRY(mg_conv_pack(lw[5], lp + o.l_wo, 2 * C, C, 1, MG_PACK_PLAIN, stream));
+        MG_TRY(copy_d2d(lp + o.l_bo, lw[6], 2 * C, st));
+        if (d->multi_speaker) MG_TRY(copy_d2d(lp + o.l_wp, lw[7], (size_t)C * H, st));
+    }
+    return MG_OK;
+}
+
+// ------------------------------------------------------------------------------------------ workspace
+struct DenWs {
+    size_t emb, h1, s, dvec, hvec, x, skip, y, h, g, sig, tnh, total;
+    size_t act_stride;  // per-layer stride of h/g/sig/tnh (0 when not saving)
+};
+
+static DenWs den_ws(const mg_denoiser_dims *d, int B, int L, int save)
+{
+    const size_t C = d->channels, NL = d->n_layers;
+    const size_t act = mg_align_up((size_t)B * C * L, 64);
+    DenWs w;
+    size_t p = 0;
+    auto take = [&](size_t n) {
+        size_t at = p;
+        p += mg_align_up(n, 64);
+        return at;
+    };
+    w.emb = take(B * C);
+    w.h1 = take(B * 4 * C);
+    w.s = take(B * C);
+    w.dvec = take(NL * B * C);
+    w.hvec = d->multi_speaker ? take(NL * B * C) : w.dvec;
+    w.x = take(act);
+    w.skip = take(act);
+    w.y = take(act);
+    w.act_stride = save ? act : 0;
+    const size_t nact = save ? NL : 1;
+    w.h = take(act * nact);
+    w.g = take(act * nact);
+    w.sig = save ? take(act * nact) : 0;
+    w.tnh = save ? take(act * nact) : 0;
+    w.total = p;
+    return w;
+}
+
+extern "C" size_t mg_denoiser_workspace_floats(const mg_denoiser_dims *d, int B, int L, int save_for_backward)
+{
+    if (den_check(d) != MG_OK || B <= 0 || L <= 0) return 0;
+    return den_ws(d, B, L, save_for_backward).total;
+}
+
+// ------------------------------------------------------------------------------------------ profiling
+// HIP-event brackets around the dominant kernel (the k=3 gated conv), recorded on the launch
+// stream inside mg_denoiser_fwd while a profile session is open.  Host-side state only.
+#include <vector>
+static thread_local std::vector<hipEvent_t> g_prof_ev;  // 2 per bracket
+static thread_local int g_prof_used = 0, g_prof_cap = 0;
+
+extern "C" int mg_profile_begin(int max_brackets)
+{
+    if (max_brackets <= 0) return MG_ERR_ARG;
+    for (hipEvent_t e : g_prof_ev) (void)hipEventDestroy(e);
+    g_prof_ev.assign((size_t)2 * max_brackets, nullptr);
+    for (auto &e : g_prof_ev) {
+        hipError_t rc = hipEventCreate(&e);
+        if (rc != hipSuccess) return (int)rc;
+    }
+    g_prof_cap = max_brackets;
+    g_prof_used = 0;
+    return MG_OK;
+}
+
+// Waits for the recorded events, writes one elapsed time (ms) per bracket; returns the count (<0: error).
+extern "C" int mg_profile_end(float *ms_out, int max_out)
+{
+    int n = g_prof_used < max_out ? g_prof_used : max_out;
+    for (int i = 0; i < n; ++i) {
+        hipError_t rc = hipEventSynchronize(g_prof_ev[2 * i + 1]);
+        if (rc == hipSuccess) rc = hipEventElapsedTime(&ms_out[i], g_prof_ev[2 * i], g_prof_ev[2 * i + 1]);
+        if (rc != hipSuccess) { n = -(int)rc; break; }
+    }
+    for (hipEvent_t e : g_prof_ev) (void)hipEventDestroy(e);
+    g_prof_ev.clear();
+    g_prof_cap = g_prof_used = 0;
+    return n;
+}
+
+static inline void prof_mark(hipStream_t st, int which)
+{
+    if (g_prof_used < g_prof_cap) {
+        (void)hipEventRecord(g_prof_ev[2 * g_prof_used + which], st);
+        if (which) ++g_prof_used;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ forward
+extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, const float *x_t, const int64_t *t,
+                               const float *cond, const float *spk, float *out, float *ws, size_t ws_floats, int B,
+                               int L, int save, void *stream)
+{
+    MG_TRY(den_check(d));
+    if (!packed || !x_t || !t || !cond || !out || !ws) return MG_ERR_ARG;
+    if (d->multi_speaker && !spk) return MG_ERR_ARG;
+    if (B <= 0 || L <= 0) return MG_ERR_SHAPE;
+    const DenWs w = den_ws(d, B, L, save);
+    if (ws_floats < w.total) return MG_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int C = d->channels, H = d->cond_channels, M = d->mel_bins, NL = d->n_layers;
+    const DenLayout o = den_layout(d);
+    const float *lay0 = packed + o.layers;
+
+    // step embedding -> MLP -> per-layer projections (model/modules.py:433-434, blocks.py:1159)
+    hipLaunchKernelGGL(step_embed_kernel, dim3(mg_cdiv(B * (C / 2), 256)), dim3(256), 0, st, t, packed + o.freq,
+                       ws + w.emb, B, C);
+    MG_LAUNCH_CHECK();
+    MG_TRY(small_linear(packed + o.mlp0, 0, ws + w.emb, ws + w.h1, 0, nullptr, 0, B, 4 * C, C, 1, 1, st));
+    MG_TRY(small_linear(packed + o.mlp2, 0, ws + w.h1, ws + w.s, 0, nullptr, 0, B, C, 4 * C, 1, 0, st));
+    MG_TRY(small_linear(lay0 + o.l_wd, (long)o.layer_stride, ws + w.s, ws + w.dvec, (long)B * C, nullptr, 0, B, C, C, NL,
+                        0, st));
+    if (d->multi_speaker)
+        MG_TRY(small_linear(lay0 + o.l_wp, (long)o.layer_stride, spk, ws + w.hvec, (long)B * C, ws + w.dvec,
+                            (long)B * C, B, C, H, NL, 0, st));
+
+    // input projection + ReLU (model/modules.py:430-431; the second relu is idempotent)
+    {
+        ConvShape s{B, M, L, L, 1, 1, 0, C, 0, 0};
+        EpiBiasAct::Params ep{ws + w.x, packed + o.in_b, nullptr, 1.f, C, MG_ACT_RELU, 0};
+        MG_TRY(conv_launch<EpiBiasAct>(s, x_t, nullptr, packed + o.in_w, ep, st));
+    }
+    for (int l = 0; l < NL; ++l) {
+        const float *lp = lay0 + (size_t)l * o.layer_stride;
+        float *hbuf = ws + w.h + (size_t)l * w.act_stride;
+        float *gbuf = ws + w.g + (size_t)l * w.act_stride;
+        {
+            ConvShape s{B, H, L, L, 1, 1, 0, C, 0, 0};
+            EpiCond::Params ep{hbuf, lp + o.l_bc, ws + w.x, ws + w.hvec + (size_t)l * B * C, C};
+            MG_TRY(conv_launch<EpiCond>(s, cond, nullptr, lp + o.l_wc, ep, st));
+        }
+        {
+            ConvShape s{B, C, L, L, 3, 1, 1, 2 * C, 0, 0};
+            EpiGate::Params ep{gbuf, lp + o.l_b3, save ? ws + w.sig + (size_t)l * w.act_stride : nullptr,
+                               save ? ws + w.tnh + (size_t)l * w.act_stride : nullptr, C};
+            prof_mark(st, 0);
+            MG_TRY(conv_launch<EpiGate>(s, hbuf, nullptr, lp + o.l_w3, ep, st));
+            prof_mark(st, 1);
+        }
+        {
+            ConvShape s{B, C, L, L, 1, 1, 0, 2 * C, 0, 0};
+            EpiResSkip::Params ep{ws + w.x, ws + w.skip, lp + o.l_bo, ws + w.dvec + (size_t)l * B * C, C, l == 0};
+            MG_TRY(conv_launch<EpiResSkip>(s, gbuf, nullptr, lp + o.l_wo, ep, st));
+        }
+    }
+    // sum(skips)/sqrt(NL) -> skip_projection -> ReLU -> output_projection (model/modules.py:441-444)
+    {
+        ConvShape s{B, C, L, L, 1, 1, 0, C, 0, 0};
+        EpiBiasAct::Params ep{ws + w.y, packed + o.skip_b, nullptr, 1.0f / sqrtf((float)NL), C, MG_ACT_RELU, 0};
+        MG_TRY(conv_launch<EpiBiasAct>(s, ws + w.skip, nullptr, packed + o.skip_w, ep, st));
+    }
+    {
+        ConvShape s{B, C, L, L, 1, 1, 0, M, 0, 0};
+        EpiBiasAct::Params ep{out, packed + o.out_b, nullptr, 1.f, M, MG_ACT_NONE, 0};
+        MG_TRY(conv_launch<EpiBiasAct>(s, ws + w.y, nullptr, packed + o.out_w, ep, st));
+    }
+    return MG_OK;
+}

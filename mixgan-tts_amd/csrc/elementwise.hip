@@ -1,0 +1,300 @@
+// HBM-bound diffusion algebra: diffuse_fn/q_sample, q_posterior_sample, (de)norm + transposes.
+// One pass over each tensor, 16-byte accesses where the row pitch allows, LDS-tiled transposes so
+// that both the [B,L,M] side and the [B,M,L] side are read/written in full 256-byte segments.
+#include "common.h"
+
+#define TL 64  // frames per transpose tile
+
+// norm_spec, exactly the reference's op order (model/diffusion.py:228-229)
+__device__ __forceinline__ float norm1(float x, float mn, float mx) { return (x - mn) / (mx - mn) * 2.f - 1.f; }
+// denorm_spec (model/diffusion.py:231-232)
+__device__ __forceinline__ float denorm1(float x, float mn, float mx) { return (x + 1.f) / 2.f * (mx - mn) + mn; }
+
+// ---------------------------------------------------------------------------------------------
+// mel [B,L,M] -> x_t [B,M,L]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void diffuse_kernel(const float *__restrict__ mel, const int64_t *__restrict__ t,
+                                                      const float *__restrict__ noise,
+                                                      const uint8_t *__restrict__ keep,
+                                                      const float *__restrict__ spec_min,
+                                                      const float *__restrict__ spec_max,
+                                                      const float *__restrict__ sqrt_ac,
+                                                      const float *__restrict__ sqrt_1mac, float *__restrict__ out,
+                                                      int L, int M, int T)
+{
+    extern __shared__ float tile[];  // [TL][M+1]
+    const int b = blockIdx.y;
+    const int l0 = blockIdx.x * TL;
+    const int nl = min(TL, L - l0);
+    const int P = M + 1;
+    const float *src = mel + ((size_t)b * L + l0) * M;
+    for (int idx = threadIdx.x; idx < nl * M; idx += 256) {
+        const int l = idx / M, m = idx - l * M;
+        tile[l * P + m] = norm1(src[idx], spec_min[m], spec_max[m]);
+    }
+    __syncthreads();
+    long tb = t[b];
+    const bool clean = tb < 0;  // model/diffusion.py:180-184: x_{-1} is the ground-truth mel
+    if (tb < 0) tb = 0;
+    if (tb >= T) tb = T - 1;
+    const float ca = sqrt_ac[tb], cb = sqrt_1mac[tb];
+    for (int idx = threadIdx.x; idx < M * TL; idx += 256) {
+        const int m = idx / TL, l = idx - m * TL;
+        if (l >= nl) continue;
+        const size_t o = ((size_t)b * M + m) * L + l0 + l;
+        const float x0 = tile[l * P + m];
+        float v = clean ? x0 : ca * x0 + cb * noise[o];
+        if (keep) v *= (float)keep[(size_t)b * L + l0 + l];
+        out[o] = v;
+    }
+}
+
+extern "C" int mg_diffuse_fwd(const float *mel, const int64_t *t, const float *noise, const uint8_t *keep,
+                              const float *spec_min, const float *spec_max, const float *sqrt_ac,
+                              const float *sqrt_1mac, float *out, int B, int L, int M, int T, void *stream)
+{
+    if (!mel || !t || !noise || !spec_min || !spec_max || !sqrt_ac || !sqrt_1mac || !out) return MG_ERR_ARG;
+    if (B <= 0 || L <= 0 || M <= 0 || M > 1024 || T <= 0) return MG_ERR_SHAPE;
+    dim3 grid(mg_cdiv(L, TL), B);
+    hipLaunchKernelGGL(diffuse_kernel, grid, dim3(256), (size_t)TL * (M + 1) * sizeof(float), (hipStream_t)stream, mel,
+                       t, noise, keep, spec_min, spec_max, sqrt_ac, sqrt_1mac, out, L, M, T);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// posterior sample, all tensors [B,M,L]
+// ---------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void posterior_kernel(const float *__restrict__ x0, const float *__restrict__ xt,
+                                                        const int64_t *__restrict__ t,
+                                                        const float *__restrict__ noise,
+                                                        const uint8_t *__restrict__ keep,
+                                                        const float *__restrict__ coef1,
+                                                        const float *__restrict__ coef2,
+                                                        const float *__restrict__ logvar, float *__restrict__ out,
+                                                        float *__restrict__ x0c_out, int clip, int L, int ML, int T)
+{
+    // grid.y = batch; grid.x strides over M*L/V vectors of this batch element
+    const int b = blockIdx.y;
+    long tb = t[b];
+    if (tb < 0) tb = 0;
+    if (tb >= T) tb = T - 1;
+    const float c1 = coef1[tb], c2 = coef2[tb];
+    const float sg = tb == 0 ? 0.f : expf(0.5f * logvar[tb]);
+    const size_t base = (size_t)b * ML;
+    const int nvec = ML / V;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nvec; i += gridDim.x * 256) {
+        const int e0 = i * V;
+        float a[V], x[V], n[V], k[V];
+        if (V == 4) {
+            const f32x4 av = *reinterpret_cast<const f32x4 *>(x0 + base + e0);
+            const f32x4 xv = *reinterpret_cast<const f32x4 *>(xt + base + e0);
+            const f32x4 nv = *reinterpret_cast<const f32x4 *>(noise + base + e0);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                a[j] = av[j];
+                x[j] = xv[j];
+                n[j] = nv[j];
+            }
+        } else {
+            a[0] = x0[base + e0];
+            x[0] = xt[base + e0];
+            n[0] = noise[base + e0];
+        }
+        const int l = e0 % L;  // V divides L on the vector path, so the V elements share a row
+#pragma unroll
+        for (int j = 0; j < V; ++j) k[j] = keep ? (float)keep[(size_t)b * L + l + j] : 1.f;
+        float o[V], ac[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float s = a[j] * k[j];
+            if (clip) s = fminf(fmaxf(s, -1.f), 1.f);
+            ac[j] = s;
+            o[j] = (c1 * s + c2 * x[j] + sg * n[j]) * k[j];
+        }
+        if (V == 4) {
+            f32x4 ov = {o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<f32x4 *>(out + base + e0) = ov;
+            if (x0c_out) {
+                f32x4 cv = {ac[0], ac[1], ac[2], ac[3]};
+                *reinterpret_cast<f32x4 *>(x0c_out + base + e0) = cv;
+            }
+        } else {
+            out[base + e0] = o[0];
+            if (x0c_out) x0c_out[base + e0] = ac[0];
+        }
+    }
+}
+
+extern "C" int mg_posterior_sample_fwd(const float *x0, const float *x_t, const int64_t *t, const float *noise,
+                                       const uint8_t *keep, const float *coef1, const float *coef2,
+                                       const float *logvar, float *out, float *x0_clamped_out, int clip, int B, int L,
+                                       int M, int T, void *stream)
+{
+    if (!x0 || !x_t || !t || !noise || !coef1 || !coef2 || !logvar || !out) return MG_ERR_ARG;
+    if (B <= 0 || L <= 0 || M <= 0 || T <= 0) return MG_ERR_SHAPE;
+    const int ML = M * L;
+    const bool vec = (L % 4 == 0) && ((((uintptr_t)x0 | (uintptr_t)x_t | (uintptr_t)noise | (uintptr_t)out |
+                                        (uintptr_t)x0_clamped_out) & 15) == 0);
+    const int V = vec ? 4 : 1;
+    dim3 grid(min(mg_cdiv(ML / V, 256), 512), B);
+    if (vec)
+        hipLaunchKernelGGL(posterior_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x0, x_t, t, noise, keep, coef1,
+                           coef2, logvar, out, x0_clamped_out, clip, L, ML, T);
+    else
+        hipLaunchKernelGGL(posterior_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x0, x_t, t, noise, keep, coef1,
+                           coef2, logvar, out, x0_clamped_out, clip, L, ML, T);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// [B,M,L] <-> [B,L,M] with optional norm/denorm and keep mask
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                        const float *__restrict__ spec_min,
+                                                        const float *__restrict__ spec_max,
+                                                        const uint8_t *__restrict__ keep, int to_blm, int mode, int L,
+                                                        int M)
+{
+    extern __shared__ float tile[];  // [TL][M+1]
+    const int b = blockIdx.y;
+    const int l0 = blockIdx.x * TL;
+    const int nl = min(TL, L - l0);
+    const int P = M + 1;
+    if (to_blm) {
+        // read [M][nl] rows of the BML tensor
+        for (int idx = threadIdx.x; idx < M * TL; idx += 256) {
+            const int m = idx / TL, l = idx - m * TL;
+            if (l < nl) tile[l * P + m] = in[((size_t)b * M + m) * L + l0 + l];
+        }
+        __syncthreads();
+        float *dst = out + ((size_t)b * L + l0) * M;
+        for (int idx = threadIdx.x; idx < nl * M; idx += 256) {
+            const int l = idx / M, m = idx - l * M;
+            float v = tile[l * P + m];
+            if (mode == 2) v = denorm1(v, spec_min[m], spec_max[m]);
+            if (keep) v *= (float)keep[(size_t)b * L + l0 + l];
+            dst[idx] = v;
+        }
+    } else {
+        const float *src = in + ((size_t)b * L + l0) * M;
+        for (int idx = threadIdx.x; idx < nl * M; idx += 256) {
+            const int l = idx / M, m = idx - l * M;
+            float v = src[idx];
+            if (mode == 1) v = norm1(v, spec_min[m], spec_max[m]);
+            tile[l * P + m] = v;
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < M * TL; idx += 256) {
+            const int m = idx / TL, l = idx - m * TL;
+            if (l >= nl) continue;
+            float v = tile[l * P + m];
+            if (keep) v *= (float)keep[(size_t)b * L + l0 + l];
+            out[((size_t)b * M + m) * L + l0 + l] = v;
+        }
+    }
+}
+
+extern "C" int mg_transpose_bml(const float *in, float *out, const float *spec_min, const float *spec_max,
+                                const uint8_t *keep, int to_blm, int mode, int B, int L, int M, void *stream)
+{
+    if (!in || !out) return MG_ERR_ARG;
+    if (mode < 0 || mode > 2 || (mode != 0 && (!spec_min || !spec_max))) return MG_ERR_ARG;
+    if (B <= 0 || L <= 0 || M <= 0 || M > 1024) return MG_ERR_SHAPE;
+    dim3 grid(mg_cdiv(L, TL), B);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), (size_t)TL * (M + 1) * sizeof(float), (hipStream_t)stream, in,
+                       out, spec_min, spec_max, keep, to_blm, mode, L, M);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// norm_spec / denorm_spec on [..., M] tensors and their gradients
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spec_affine_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                          const float *__restrict__ spec_min,
+                                                          const float *__restrict__ spec_max, int mode, size_t n, int M)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i % M);
+        const float mn = spec_min[m], mx = spec_max[m], v = in[i];
+        float r;
+        if (mode == 1) r = norm1(v, mn, mx);
+        else if (mode == 2) r = denorm1(v, mn, mx);
+        else if (mode == 3) r = v / (mx - mn) * 2.f;   // d norm_spec / dx
+        else r = v / 2.f * (mx - mn);                  // d denorm_spec / dx
+        out[i] = r;
+    }
+}
+
+extern "C" int mg_spec_affine(const float *in, float *out, const float *spec_min, const float *spec_max, int mode,
+                              size_t n, int M, void *stream)
+{
+    if (!in || !out || !spec_min || !spec_max) return MG_ERR_ARG;
+    if (mode < 1 || mode > 4) return MG_ERR_ARG;
+    if (M <= 0) return MG_ERR_SHAPE;
+    if (n == 0) return MG_OK;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(spec_affine_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, spec_min, spec_max,
+                       mode, n, M);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// gradient of mg_posterior_sample_fwd w.r.t. x0 (the only differentiable input on the path)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void posterior_bwd_kernel(const float *__restrict__ x0,
+                                                            const int64_t *__restrict__ t,
+                                                            const uint8_t *__restrict__ keep,
+                                                            const float *__restrict__ coef1,
+                                                            const float *__restrict__ g_x0c,
+                                                            const float *__restrict__ g_xpp, float *__restrict__ gx0,
+                                                            int clip, int L, int ML, int T)
+{
+    const int b = blockIdx.y;
+    long tb = t[b];
+    if (tb < 0) tb = 0;
+    if (tb >= T) tb = T - 1;
+    const float c1 = coef1[tb];
+    const size_t base = (size_t)b * ML;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ML; i += gridDim.x * 256) {
+        const float k = keep ? (float)keep[(size_t)b * L + (i % L)] : 1.f;
+        const float s = x0[base + i] * k;
+        const bool pass = !clip || (s >= -1.f && s <= 1.f);  // torch.clamp passes the gradient on [min, max]
+        float g = g_x0c ? g_x0c[base + i] : 0.f;
+        if (g_xpp) g += c1 * k * g_xpp[base + i];
+        gx0[base + i] = pass ? g * k : 0.f;
+    }
+}
+
+extern "C" int mg_posterior_sample_bwd(const float *x0, const int64_t *t, const uint8_t *keep, const float *coef1,
+                                       const float *g_x0c, const float *g_xpp, float *g_x0, int clip, int B, int L,
+                                       int M, int T, void *stream)
+{
+    if (!x0 || !t || !coef1 || !g_x0 || (!g_x0c && !g_xpp)) return MG_ERR_ARG;
+    if (B <= 0 || L <= 0 || M <= 0 || T <= 0) return MG_ERR_SHAPE;
+    dim3 grid(min(mg_cdiv(M * L, 256), 512), B);
+    hipLaunchKernelGGL(posterior_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x0, t, keep, coef1, g_x0c, g_xpp,
+                       g_x0, clip, L, M * L, T);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int mg_version(void) { return MG_VERSION; }
+
+extern "C" const char *mg_error_string(int code)
+{
+    switch (code) {
+    case MG_OK: return "ok";
+    case MG_ERR_ARG: return "invalid argument (null pointer or bad enum)";
+    case MG_ERR_SHAPE: return "unsupported shape";
+    case MG_ERR_WORKSPACE: return "workspace too small";
+    default: break;
+    }
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "unknown error";
+}

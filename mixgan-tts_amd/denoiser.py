@@ -1,0 +1,117 @@
+"""Denoiser (model/modules.py:382-446): same constructor, state_dict keys and forward
+signature as the reference; the forward is one call into `mg_denoiser_fwd`."""
+import ctypes
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import fptr, iptr, check, stream_ptr, DenoiserDims
+from .blocks import ConvNorm, LinearNorm, Mish, DiffusionEmbedding, ResidualBlock
+
+
+class Denoiser(nn.Module):
+    """Conditional diffusion denoiser -- drop-in for `model.modules.Denoiser`."""
+
+    def __init__(self, preprocess_config, model_config):
+        super().__init__()
+        n_mel_channels = preprocess_config["preprocessing"]["mel"]["n_mel_channels"]
+        d_encoder = model_config["transformer"]["encoder_hidden"]
+        residual_channels = model_config["denoiser"]["residual_channels"]
+        residual_layers = model_config["denoiser"]["residual_layers"]
+        dropout = model_config["denoiser"]["denoiser_dropout"]
+        multi_speaker = model_config["multi_speaker"]
+        self.multi_speaker = bool(multi_speaker)
+
+        self.input_projection = nn.Sequential(ConvNorm(n_mel_channels, residual_channels, kernel_size=1), nn.ReLU())
+        self.diffusion_embedding = DiffusionEmbedding(residual_channels)
+        self.mlp = nn.Sequential(
+            LinearNorm(residual_channels, residual_channels * 4),
+            Mish(),
+            LinearNorm(residual_channels * 4, residual_channels),
+        )
+        self.residual_layers = nn.ModuleList(
+            [ResidualBlock(d_encoder, residual_channels, dropout=dropout, multi_speaker=multi_speaker)
+             for _ in range(residual_layers)])
+        self.skip_projection = ConvNorm(residual_channels, residual_channels, kernel_size=1)
+        self.output_projection = ConvNorm(residual_channels, n_mel_channels, kernel_size=1)
+        nn.init.zeros_(self.output_projection.conv.weight)  # model/modules.py:418
+
+        self._dims = DenoiserDims(residual_layers, residual_channels, d_encoder, n_mel_channels, int(self.multi_speaker))
+        self._packed = None
+        self._packed_key = None
+        self._ws = {}
+
+    # ------------------------------------------------------------------ packed-weight cache
+    def _weight_table(self):
+        """Pointer-table order of include/mixgan_hip.h (mg_denoiser_pack)."""
+        t = [self.input_projection[0].conv.weight, self.input_projection[0].conv.bias,
+             self.mlp[0].linear.weight, self.mlp[2].linear.weight,
+             self.skip_projection.conv.weight, self.skip_projection.conv.bias,
+             self.output_projection.conv.weight, self.output_projection.conv.bias]
+        for blk in self.residual_layers:
+            t += [blk.conv_layer.conv.weight, blk.conv_layer.conv.bias, blk.diffusion_projection.linear.weight,
+                  blk.conditioner_projection.conv.weight, blk.conditioner_projection.conv.bias,
+                  blk.output_projection.conv.weight, blk.output_projection.conv.bias,
+                  blk.speaker_projection.linear.weight if self.multi_speaker else None, None]
+        return t
+
+    def packed_weights(self):
+        """The MFMA-ordered weight blob: a derived cache, rebuilt when any parameter changes
+        (optimizer step, load_state_dict, .to())."""
+        table = self._weight_table()
+        key = tuple((p.data_ptr(), p._version) for p in table if p is not None)
+        if self._packed is None or key != self._packed_key:
+            L = _lib.lib()
+            dev = table[0].device
+            if dev.type != "cuda":
+                raise _lib.MixganHipError("Denoiser parameters are on %s: the HIP path needs them on the GPU" % dev)
+            n = L.mg_denoiser_packed_floats(ctypes.byref(self._dims))
+            if self._packed is None or self._packed.numel() != n or self._packed.device != dev:
+                self._packed = torch.empty(n, device=dev, dtype=torch.float32)
+            ptrs = (ctypes.c_void_p * len(table))(*[None if p is None else fptr(p.detach()).value for p in table])
+            freq = self.diffusion_embedding.frequencies(dev).contiguous()
+            check(L.mg_denoiser_pack(ctypes.byref(self._dims), ptrs, fptr(freq), fptr(self._packed), stream_ptr()))
+            self._packed_key = key
+        return self._packed
+
+    def _workspace(self, B, L, save, dev):
+        k = (B, L, bool(save), dev)
+        ws = self._ws.get(k)
+        if ws is None:
+            n = _lib.lib().mg_denoiser_workspace_floats(ctypes.byref(self._dims), B, L, int(save))
+            if len(self._ws) > 8:
+                self._ws.clear()
+            ws = torch.empty(n, device=dev, dtype=torch.float32)
+            self._ws[k] = ws
+        return ws
+
+    # ------------------------------------------------------------------ forward
+    def run(self, x_t, t, cond, spk, out=None, save=False, packed=None):
+        """x_t [B,M,L], t int64 [B], cond [B,H,L] contiguous, spk [B,H]|None -> [B,M,L] (no autograd)."""
+        B, M, L = x_t.shape
+        if packed is None:
+            packed = self.packed_weights()
+        ws = self._workspace(B, L, save, x_t.device)
+        if out is None:
+            out = torch.empty_like(x_t)
+        check(_lib.lib().mg_denoiser_fwd(ctypes.byref(self._dims), fptr(packed), fptr(x_t), iptr(t, torch.int64),
+                                         fptr(cond), fptr(spk, not self.multi_speaker), fptr(out), fptr(ws),
+                                         ws.numel(), B, L, int(save), stream_ptr()))
+        return out
+
+    def forward(self, mel, diffusion_step, conditioner, speaker_emb, mask=None):
+        """mel [B,1,M,T], diffusion_step [B], conditioner [B,H,T], speaker_emb [B,H]|None -> [B,1,M,T]."""
+        if not mel.is_cuda:
+            raise _lib.MixganHipError("Denoiser.forward on %s: the HIP path has no CPU fallback" % mel.device)
+        x = mel[:, 0].contiguous()
+        t = diffusion_step.to(torch.int64).contiguous()
+        cond = conditioner.contiguous()
+        spk = speaker_emb.contiguous() if (self.multi_speaker and speaker_emb is not None) else None
+        needs_grad = torch.is_grad_enabled() and (
+            x.requires_grad or cond.requires_grad or (spk is not None and spk.requires_grad)
+            or any(p.requires_grad for p in self.parameters()))
+        if needs_grad:
+            from .autograd import DenoiserFn
+            return DenoiserFn.apply(self, x, t, cond, spk, *[p for p in self._weight_table() if p is not None])[:, None]
+        return self.run(x, t, cond, spk)[:, None]

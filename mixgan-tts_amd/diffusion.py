@@ -1,0 +1,201 @@
+"""GaussianDiffusion (model/diffusion.py:38-235): same constructor, buffers, state_dict keys,
+forward/sampling signatures and hidden `cond`/`spk_emb` stash as the reference; all tensor
+math runs in the HIP library.
+
+Differences a caller can see (all opt-in or documented in DESIGN.md):
+  * `noise_fn` -- optional callable(shape)->tensor replacing `torch.randn` so tests can inject
+    the reference's exact draws (GPU and CPU generators differ); `t_fn` likewise for randint;
+  * `sampling(noise=None, keep_trace=True)`: keep_trace=False returns only the final mel
+    instead of the reference's T+1 retained tensors;
+  * no tqdm progress bars in the sampling loop (they force a host iteration per step).
+"""
+import json
+import os
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops, _lib
+from .denoiser import Denoiser
+from .schedule import beta_schedule, diffusion_buffers, BUFFER_NAMES
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(self, args, preprocess_config, model_config, train_config):
+        super().__init__()
+        self.model = args.model
+        self.denoise_fn = Denoiser(preprocess_config, model_config)
+        self.mel_bins = preprocess_config["preprocessing"]["mel"]["n_mel_channels"]
+        den = model_config["denoiser"]
+        betas = beta_schedule(
+            den["noise_schedule_naive"],
+            den["timesteps" if self.model == "naive" else "shallow_timesteps"],
+            min_beta=den["min_beta"], max_beta=den["max_beta"], s=den["s"])
+        self.num_timesteps = int(betas.shape[0])
+        self.loss_type = train_config["loss"]["noise_loss"]
+        bufs = diffusion_buffers(betas)
+        for k in BUFFER_NAMES:
+            self.register_buffer(k, torch.tensor(bufs[k], dtype=torch.float32))
+        with open(os.path.join(preprocess_config["path"]["preprocessed_path"], "stats.json")) as f:
+            stats = json.load(f)
+        keep = den["keep_bins"]
+        self.register_buffer("spec_min", torch.FloatTensor(stats["spec_min"])[None, None, :keep])
+        self.register_buffer("spec_max", torch.FloatTensor(stats["spec_max"])[None, None, :keep])
+        self.noise_fn = None
+        self.t_fn = None
+        self.cond = None
+        self.spk_emb = None
+
+    # ------------------------------------------------------------------ helpers
+    def _buf(self):
+        return {k: getattr(self, k) for k in BUFFER_NAMES + ("spec_min", "spec_max")}
+
+    def _randn(self, shape, device):
+        if self.noise_fn is not None:
+            return self.noise_fn(tuple(shape)).to(device=device, dtype=torch.float32).contiguous()
+        return torch.randn(shape, device=device)
+
+    def _randint(self, B, device):
+        if self.t_fn is not None:
+            return self.t_fn((B,)).to(device=device, dtype=torch.int64).contiguous()
+        return torch.randint(0, self.num_timesteps, (B,), device=device).long()
+
+    @staticmethod
+    def _bml(x4):
+        """[B,1,M,L] view of the reference layout -> our contiguous [B,M,L]."""
+        return x4[:, 0].contiguous()
+
+    # ------------------------------------------------------------------ reference surface
+    def norm_spec(self, x):
+        from .autograd import spec_affine
+        return spec_affine(x, self.spec_min, self.spec_max, True)
+
+    def denorm_spec(self, x):
+        from .autograd import spec_affine
+        return spec_affine(x, self.spec_min, self.spec_max, False)
+
+    def out2mel(self, x):
+        return x
+
+    def q_sample(self, x_start, t, noise=None):
+        """x_start [B,1,M,L] already normalised (model/diffusion.py:147-153)."""
+        x = self._bml(x_start)
+        B, M, L = x.shape
+        noise = self._randn((B, 1, M, L), x.device) if noise is None else noise
+        mel_like = ops.transpose_bml(x, True)            # the kernel takes the [B,L,M] side
+        ident = {**self._buf(), "spec_min": torch.full_like(self.spec_min, -1.0),
+                 "spec_max": torch.full_like(self.spec_max, 1.0)}       # norm_spec == identity
+        return ops.diffuse(mel_like, t.clamp(min=0).contiguous(), self._bml(noise), None, ident)[:, None]
+
+    def diffuse_fn(self, x_start, t, noise=None, keep=None):
+        """mel [B,L,M] -> x_t [B,1,M,L] (model/diffusion.py:177-185); t<0 rows return the clean mel."""
+        B, L, M = x_start.shape
+        noise = self._randn((B, 1, M, L), x_start.device) if noise is None else noise
+        out = ops.diffuse(x_start.contiguous(), t.contiguous(), self._bml(noise), keep, self._buf())
+        t[t < 0] = 0                                      # the reference mutates its argument
+        return out[:, None]
+
+    def q_posterior_sample(self, x_start, x_t, t, repeat_noise=False, keep=None, clip=False):
+        """model/diffusion.py:113-119 on [B,1,M,L] tensors."""
+        B, _, M, L = x_t.shape
+        noise = self._randn((B, 1, M, L), x_t.device)
+        return ops.posterior_sample(self._bml(x_start), self._bml(x_t), t.contiguous(), self._bml(noise), keep,
+                                    self._buf(), clip=clip)[:, None]
+
+    @torch.no_grad()
+    def p_sample(self, x_t, t, cond, spk_emb, clip_denoised=True, repeat_noise=False):
+        """model/diffusion.py:121-129; x_t [B,1,M,L], cond [B,H,L]."""
+        x = self._bml(x_t)
+        x0 = self.denoise_fn.run(x, t.contiguous(), cond.contiguous(), spk_emb)
+        B, M, L = x.shape
+        noise = self._bml(self._randn((B, 1, M, L), x.device))
+        return ops.posterior_sample(x0, x, t.contiguous(), noise, None, self._buf(), clip=clip_denoised)[:, None]
+
+    @torch.no_grad()
+    def sampling(self, noise=None, keep_trace=True):
+        """Reverse process from the stashed cond/spk (model/diffusion.py:155-165).
+        Returns the list of denormalised mels [B,L,M] (T+1 entries, or only the last)."""
+        cond = self.cond
+        B, _, L = cond.shape
+        dev = cond.device
+        M, T = self.mel_bins, self.num_timesteps
+        buf = self._buf()
+        den = self.denoise_fn
+        packed = den.packed_weights()
+        x = self._bml(self._randn((B, 1, M, L), dev) if noise is None else noise)
+        xs = [x] if keep_trace else None
+        x0 = torch.empty_like(x)
+        for i in reversed(range(T)):
+            t = torch.full((B,), i, device=dev, dtype=torch.long)
+            den.run(x, t, cond, self.spk_emb, out=x0, packed=packed)
+            nz = self._bml(self._randn((B, 1, M, L), dev))
+            x = ops.posterior_sample(x0, x, t, nz, None, buf, clip=True)
+            if keep_trace:
+                xs.append(x)
+        outs = xs if keep_trace else [x]
+        return [ops.transpose_bml(a, True, 2, self.spec_min, self.spec_max) for a in outs]
+
+    def diffuse_trace(self, x_start, mask):
+        """aux only (model/diffusion.py:167-175): mask True = pad."""
+        B, L, M = x_start.shape
+        keep = (~mask).to(torch.uint8).contiguous()
+        first = self.norm_spec(x_start).clamp_(-1.0, 1.0) * (~mask).unsqueeze(-1)
+        trace = [first]
+        for i in range(self.num_timesteps):
+            t = torch.full((B,), i, device=x_start.device, dtype=torch.long)
+            x = self.diffuse_fn(x_start, t, keep=keep)
+            trace.append(ops.transpose_bml(self._bml(x), True))
+        return trace
+
+    def forward(self, mel, cond, spk_emb, mel_mask, coarse_mel=None, clip_denoised=True):
+        """model/diffusion.py:187-226.  mel [B,L,M]|None, cond [B,L,H], mel_mask bool [B,L] True = pad."""
+        B = cond.shape[0]
+        dev = cond.device
+        if dev.type != "cuda":
+            raise _lib.MixganHipError("GaussianDiffusion.forward on %s: the HIP path has no CPU fallback" % dev)
+        x_t = x_t_prev = x_t_prev_pred = t = None
+        keep = (~mel_mask).to(torch.uint8).contiguous()
+        spk = spk_emb.contiguous() if spk_emb is not None else None
+        grad = torch.is_grad_enabled() and mel is not None and (
+            cond.requires_grad or (spk is not None and spk.requires_grad)
+            or any(p.requires_grad for p in self.denoise_fn.parameters()))
+        if grad:
+            from .autograd import transpose_to_bml
+            cond_t = transpose_to_bml(cond.contiguous())
+        else:
+            cond_t = ops.transpose_bml(cond.detach().contiguous(), False)
+        self.cond = cond_t.detach()
+        self.spk_emb = spk.detach() if spk is not None else None
+        buf = self._buf()
+        if mel is None:
+            if self.model != "shallow":
+                noise = None
+            else:
+                t = torch.full((B,), self.num_timesteps - 1, device=dev, dtype=torch.long)
+                noise = self.diffuse_fn(coarse_mel, t, keep=keep)
+            x_0_pred = self.sampling(noise=noise, keep_trace=False)[-1] * (~mel_mask).unsqueeze(-1)
+            return x_0_pred, x_t, x_t_prev, x_t_prev_pred, t
+        M, L = mel.shape[2], mel.shape[1]
+        t = self._randint(B, dev)
+        melc = mel.contiguous()
+        x_t_b = ops.diffuse(melc, t, self._bml(self._randn((B, 1, M, L), dev)), keep, buf)
+        x_prev_b = ops.diffuse(melc, (t - 1).contiguous(), self._bml(self._randn((B, 1, M, L), dev)), keep, buf)
+        post_noise = self._bml(self._randn((B, 1, M, L), dev))
+        if grad:
+            from .autograd import denoise_and_posterior
+            x0c, xpp = denoise_and_posterior(self, x_t_b, t, cond_t, spk, post_noise, keep, clip_denoised,
+                                             coarse_mel if self.model == "shallow" else None)
+            from .autograd import transpose_to_blm
+            return (transpose_to_blm(x0c), ops.transpose_bml(x_t_b, True), ops.transpose_bml(x_prev_b, True),
+                    transpose_to_blm(xpp), t)
+        x0 = self.denoise_fn.run(x_t_b, t, cond_t, spk)
+        if self.model != "shallow":
+            xpp, x0c = ops.posterior_sample(x0, x_t_b, t, post_noise, keep, buf, clip=clip_denoised, want_x0c=True)
+        else:
+            # shallow: the posterior starts from the (detached) coarse mel, x0 is only masked+clamped
+            start = ops.transpose_bml(coarse_mel.detach().contiguous(), False, 1, self.spec_min, self.spec_max)
+            xpp = ops.posterior_sample(start, x_t_b, t, post_noise, keep, buf, clip=False)
+            _, x0c = ops.posterior_sample(x0, x_t_b, t, post_noise, keep, buf, clip=clip_denoised, want_x0c=True)
+        tb = lambda a: ops.transpose_bml(a, True)
+        return tb(x0c), tb(x_t_b), tb(x_prev_b), tb(xpp), t

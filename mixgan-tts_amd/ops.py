@@ -1,0 +1,112 @@
+"""Thin tensor-level wrappers over the C ABI (include/mixgan_hip.h).  Forward only here;
+differentiable entry points live next to the modules that own the parameters."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import fptr, iptr, check, stream_ptr
+
+ACT = {None: 0, "none": 0, "relu": 1, "lrelu": 2, "tanh": 3}
+PACK_PLAIN, PACK_GATE, PACK_DGRAD = 0, 1, 2
+
+
+def pack_conv_weight(w, mode=PACK_PLAIN):
+    """[Co, Ci, K] (or [Co, Ci]) fp32 -> MFMA-fragment-ordered cache tensor."""
+    L = _lib.lib()
+    if w.dim() == 2:
+        w = w[:, :, None]
+    w = w.detach().contiguous()
+    Co, Ci, K = w.shape
+    n = L.mg_conv_packed_floats(Co, Ci, K, mode)
+    if n == 0:
+        raise _lib.MixganHipError("unsupported conv weight shape %s" % (tuple(w.shape),))
+    out = torch.empty(n, device=w.device, dtype=torch.float32)
+    check(L.mg_conv_pack(fptr(w), fptr(out), Co, Ci, K, mode, stream_ptr()))
+    return out
+
+
+def conv1d_packed(x, packed, bias, Co, K, stride=1, padding=0, act=None, alpha=1.0, add=None, in_vec=None,
+                  out=None, accumulate=False):
+    L = _lib.lib()
+    B, Ci, Lin = x.shape
+    Lout = (Lin + 2 * padding - K) // stride + 1
+    if out is None:
+        out = torch.empty(B, Co, Lout, device=x.device, dtype=torch.float32)
+    check(L.mg_conv1d_fwd(fptr(x), fptr(in_vec, True), fptr(packed), fptr(bias, True), fptr(add, True), fptr(out),
+                          B, Ci, Lin, Co, Lout, K, stride, padding, ACT[act], float(alpha),
+                          int(accumulate), stream_ptr()))
+    return out
+
+
+def conv1d(x, weight, bias=None, stride=1, padding=0, act=None):
+    Co, _, K = weight.shape
+    return conv1d_packed(x, pack_conv_weight(weight), None if bias is None else bias.detach(), Co, K, stride,
+                         padding, act)
+
+
+def linear(x, weight, bias=None):
+    """x [..., in] -> [..., out] through the k=1 conv kernel (frames = flattened leading dims)."""
+    shp = x.shape
+    x2 = x.reshape(1, -1, shp[-1]).transpose(1, 2).contiguous()
+    y = conv1d(x2, weight[:, :, None], bias)
+    return y.transpose(1, 2).reshape(*shp[:-1], weight.shape[0])
+
+
+def diffuse(mel, t, noise, keep, buf):
+    """mg_diffuse_fwd: mel [B,L,M], noise [B,M,L] -> x_t [B,M,L]."""
+    L = _lib.lib()
+    B, Lf, M = mel.shape
+    out = torch.empty(B, M, Lf, device=mel.device, dtype=torch.float32)
+    check(L.mg_diffuse_fwd(fptr(mel), iptr(t, torch.int64), fptr(noise), iptr(keep, torch.uint8, True),
+                           fptr(buf["spec_min"]), fptr(buf["spec_max"]), fptr(buf["sqrt_alphas_cumprod"]),
+                           fptr(buf["sqrt_one_minus_alphas_cumprod"]), fptr(out), B, Lf, M,
+                           buf["sqrt_alphas_cumprod"].numel(), stream_ptr()))
+    return out
+
+
+def posterior_sample(x0, x_t, t, noise, keep, buf, clip=True, want_x0c=False, out=None):
+    L = _lib.lib()
+    B, M, Lf = x_t.shape
+    if out is None:
+        out = torch.empty_like(x_t)
+    x0c = torch.empty_like(x_t) if want_x0c else None
+    check(L.mg_posterior_sample_fwd(fptr(x0), fptr(x_t), iptr(t, torch.int64), fptr(noise),
+                                    iptr(keep, torch.uint8, True), fptr(buf["posterior_mean_coef1"]),
+                                    fptr(buf["posterior_mean_coef2"]), fptr(buf["posterior_log_variance_clipped"]),
+                                    fptr(out), fptr(x0c, True), int(clip), B, Lf, M,
+                                    buf["posterior_mean_coef1"].numel(), stream_ptr()))
+    return (out, x0c) if want_x0c else out
+
+
+def transpose_bml(x, to_blm, mode=0, spec_min=None, spec_max=None, keep=None):
+    """to_blm: [B,M,L] -> [B,L,M] (mode 2 = denorm_spec); else [B,L,M] -> [B,M,L] (mode 1 = norm_spec)."""
+    L = _lib.lib()
+    if to_blm:
+        B, M, Lf = x.shape
+        out = torch.empty(B, Lf, M, device=x.device, dtype=torch.float32)
+    else:
+        B, Lf, M = x.shape
+        out = torch.empty(B, M, Lf, device=x.device, dtype=torch.float32)
+    check(L.mg_transpose_bml(fptr(x), fptr(out), fptr(spec_min, True), fptr(spec_max, True),
+                             iptr(keep, torch.uint8, True), int(to_blm), mode, B, Lf, M, stream_ptr()))
+    return out
+
+
+def posterior_sample_bwd(x0, t, keep, coef1, g_x0c, g_xpp, clip):
+    L = _lib.lib()
+    B, M, Lf = x0.shape
+    out = torch.empty_like(x0)
+    check(L.mg_posterior_sample_bwd(fptr(x0), iptr(t, torch.int64), iptr(keep, torch.uint8, True), fptr(coef1),
+                                    fptr(g_x0c, True), fptr(g_xpp, True), fptr(out), int(clip), B, Lf, M,
+                                    coef1.numel(), stream_ptr()))
+    return out
+
+
+def spec_affine(x, spec_min, spec_max, mode):
+    L = _lib.lib()
+    M = x.shape[-1]
+    out = torch.empty_like(x)
+    check(L.mg_spec_affine(fptr(x), fptr(out), fptr(spec_min.reshape(-1)), fptr(spec_max.reshape(-1)), mode,
+                           x.numel(), M, stream_ptr()))
+    return out

@@ -67,3 +67,62 @@ def assert_digest(g, gold, key, tol):
         # corner tolerance is relative to the tensor's mean magnitude
         mean_mag = ref[1] / max(1, g.numel())
         assert np.abs(corner - c).max() <= tol * max(np.abs(c).max(), mean_mag) * 4, (key,)
+
+
+# ----------------------------------------------------------------------------------------------
+# Hot-path configuration keys (SURVEY.md section 5 "Config / flags"), LJSpeech values.
+def hot_path_configs(model="naive", T=4, mode="vpsde", multi_speaker=False, stats_dir=None, max_seq_len=1000):
+    import types
+    pre = {"preprocessing": {"mel": {"n_mel_channels": 80}, "speaker_embedder": "none"},
+           "path": {"preprocessed_path": stats_dir}}
+    mc = {
+        "transformer": {"encoder_hidden": 256, "decoder_layer": 6, "decoder_head": 2, "decoder_hidden": 256,
+                        "conv_filter_size": 1024, "conv_kernel_size": 9, "decoder_dropout": 0.2},
+        "denoiser": {"denoiser_hidden": 512, "denoiser_dropout": 0.2, "residual_layers": 20, "residual_channels": 256,
+                     "noise_schedule_naive": mode, "timesteps": T, "shallow_timesteps": T, "min_beta": 0.1,
+                     "max_beta": 40, "s": 0.008, "keep_bins": 80},
+        "discriminator": {"n_layer": 3, "n_uncond_layer": 2, "n_cond_layer": 2, "n_channels": [64, 128, 512, 128, 1],
+                          "kernel_sizes": [3, 5, 5, 5, 3], "strides": [1, 2, 2, 1, 1]},
+        "multi_speaker": multi_speaker, "max_seq_len": max_seq_len,
+    }
+    tr = {"loss": {"noise_loss": "l1", "adv_loss_mode": "lsgan", "lambda_fm": 10.0, "lambda_fm_shallow": 0.001},
+          "optimizer": {"batch_size": 8, "betas": [0.5, 0.9], "gamma": 0.999, "grad_clip_thresh": 1, "grad_acc_step": 1,
+                        "init_lr_G": 0.0001, "init_lr_D": 0.0002}}
+    return types.SimpleNamespace(model=model), pre, mc, tr
+
+
+def write_stats(tmpdir, spec_min, spec_max, n_speakers=0):
+    import json
+    with open(os.path.join(str(tmpdir), "stats.json"), "w") as f:
+        json.dump({"pitch": [-2.0, 8.0, 0.0, 1.0], "energy": [-1.5, 7.0, 0.0, 1.0],
+                   "spec_min": [float(v) for v in spec_min], "spec_max": [float(v) for v in spec_max]}, f)
+    if n_speakers:
+        with open(os.path.join(str(tmpdir), "speakers.json"), "w") as f:
+            json.dump({"spk%d" % i: i for i in range(n_speakers)}, f)
+    return str(tmpdir)
+
+
+def load_seeded(module, manifest, name, seed, prefix=""):
+    """Seed a product module with the fixture recipe through load_state_dict (checks key parity)."""
+    w = WR.draw(manifest[name]["seeded"], seed)
+    sd = module.state_dict()
+    for k, a in w.items():
+        assert prefix + k in sd, "missing state_dict key " + prefix + k
+        assert tuple(sd[prefix + k].shape) == a.shape, (k, tuple(sd[prefix + k].shape), a.shape)
+        sd[prefix + k] = torch.from_numpy(a)
+    module.load_state_dict(sd)
+    return WR.checksum(w)
+
+
+class Tape:
+    """noise_fn / t_fn stand-in replaying fixture tensors in call order."""
+
+    def __init__(self, items):
+        self.items = [torch.from_numpy(np.ascontiguousarray(a)) for a in items]
+        self.i = 0
+
+    def __call__(self, shape):
+        x = self.items[self.i]
+        self.i += 1
+        assert tuple(x.shape) == tuple(shape), (tuple(x.shape), tuple(shape))
+        return x

@@ -59,7 +59,9 @@ def manifest_of(mod):
 def seed_module(mod, seed, name):
     man = manifest_of(mod)
     MANIFEST[name] = {"seeded": man,
-                      "state_dict": {k: list(v.shape) for k, v in mod.state_dict().items()}}
+                      "state_dict": {k: list(v.shape) for k, v in mod.state_dict().items()},
+                      "state_dict_order": list(mod.state_dict().keys()),
+                      "param_order": [k for k, _ in mod.named_parameters()]}
     w = WR.draw(man, seed)
     sd = mod.state_dict()
     with torch.no_grad():
