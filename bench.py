@@ -31,7 +31,10 @@ B_PER_GPU = 16
 L_FRAMES = 1000
 MEL = 80
 FLOP_PER_FRAME = 23_805_952            # Denoiser.forward per frame
-K3_FLOP_PER_FRAME = 2 * 512 * 768      # the dominant kernel: Conv1d(256->512, k=3) of one layer
+K3_FLOP_PER_FRAME = 2 * 512 * 768      # generic path's dominant kernel: Conv1d(256->512, k=3) of one layer
+# fused path's dominant kernel = one whole residual layer (model/blocks.py:1157-1176):
+# k=3 conv 256->512 + conditioner 1x1 256->256 + output 1x1 256->512 (algorithmic; halo MFMAs not counted)
+LAYER_FLOP_PER_FRAME = 2 * 512 * 768 + 2 * 256 * 256 + 2 * 512 * 256
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
@@ -102,7 +105,8 @@ def main():
         cur = bufs[i & 1]
     n_layers = len(den.residual_layers)
     Lh = _lib.lib()
-    _lib.check(Lh.mg_profile_begin(args.steps * n_layers))
+    if not os.environ.get("MG_BENCH_NO_EVENTS"):
+        _lib.check(Lh.mg_profile_begin(args.steps * n_layers))
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -121,7 +125,10 @@ def main():
 
     if rank == 0:
         k_ms = float(np.mean(np.frombuffer(ms, dtype=np.float32)[:n_ev])) if n_ev > 0 else float("nan")
-        k_flop = K3_FLOP_PER_FRAME * B * L
+        generic = os.environ.get("MG_DENOISER_GENERIC") is not None
+        k_flop = (K3_FLOP_PER_FRAME if generic else LAYER_FLOP_PER_FRAME) * B * L
+        k_name = ("conv_mfma_kernel<K=3> 256->512 + GLU gate epilogue" if generic else
+                  "resblock_fused_kernel (one residual layer: cond 1x1 + k3 conv + gate + out 1x1 + res/skip)")
         achieved = k_flop / (k_ms * 1e-3) / 1e12
         value = world * args.steps / dt
         whole = FLOP_PER_FRAME * B * L * args.steps / dt / 1e12
@@ -133,7 +140,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: LJSpeech naive, p_sample step (Denoiser.forward + clamp + "
                                    "posterior sample), B=%d/GPU, L=%d, 80 mel, T=4 schedule" % (B, L),
                        "parallelism": "replicas x%d (batch-sharded, no collective)" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel<K=3> 256->512 + GLU gate epilogue",
+            "roofline": {"bound": "mfma", "kernel": k_name,
                          "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "kernel_ms": round(k_ms, 4), "launches_timed": int(n_ev),
@@ -156,6 +163,12 @@ def cpu_baseline(gd, B, L):
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:  # the box's CPU share (cgroup v2 quota), e.g. "1600000 100000" -> 16 cores
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(per))))
     except Exception:
         pass
     torch.set_num_threads(cores)

@@ -9,6 +9,8 @@
 // The 20 skip tensors are never materialised (the reference stacks them, model/modules.py:441);
 // a running fp32 sum is kept instead.
 #include "conv_mfma.h"
+#include "resblock_fused.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------ epilogues
 struct EpiCond {
@@ -225,13 +227,13 @@ static DenLayout den_layout(const mg_denoiser_dims *d)
         q += mg_align_up(n, 64);
         return at;
     };
-    o.l_w3 = ltake(mg_conv_packed_floats(2 * C, C, 3, MG_PACK_GATE));
-    o.l_b3 = ltake(2 * C);
-    o.l_wd = ltake((size_t)C * C);
     o.l_wc = ltake(mg_conv_packed_floats(C, H, 1, MG_PACK_PLAIN));
-    o.l_bc = ltake(C);
+    o.l_w3 = ltake(mg_conv_packed_floats(2 * C, C, 3, MG_PACK_GATE));
     o.l_wo = ltake(mg_conv_packed_floats(2 * C, C, 1, MG_PACK_PLAIN));
+    o.l_bc = ltake(C);
+    o.l_b3 = ltake(2 * C);
     o.l_bo = ltake(2 * C);
+    o.l_wd = ltake((size_t)C * C);
     o.l_wp = ltake(d->multi_speaker ? (size_t)C * H : 0);
     o.layer_stride = q;
     o.total = p + q * d->n_layers;
@@ -415,6 +417,50 @@ extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, c
         EpiBiasAct::Params ep{ws + w.x, packed + o.in_b, nullptr, 1.f, C, MG_ACT_RELU, 0};
         MG_TRY(conv_launch<EpiBiasAct>(s, x_t, nullptr, packed + o.in_w, ep, st));
     }
+    static const bool force_generic = std::getenv("MG_DENOISER_GENERIC") != nullptr;
+    const bool fused = !force_generic && C == RB_C && H == RB_C;
+    if (fused) {
+        // one launch per layer (resblock_fused.h); x ping-pongs between ws.x and ws.y
+        const bool vec4 = (L % 4 == 0) && (((uintptr_t)cond & 15) == 0);
+        float *xa = ws + w.x, *xb = ws + w.y;
+        for (int l = 0; l < NL; ++l) {
+            const float *lp = lay0 + (size_t)l * o.layer_stride;
+            ResArgs a;
+            a.cond = cond;
+            a.x_in = xa;
+            a.x_out = xb;
+            a.skip = ws + w.skip;
+            a.wc = lp + o.l_wc;
+            a.w3 = lp + o.l_w3;
+            a.wo = lp + o.l_wo;
+            a.bc = lp + o.l_bc;
+            a.b3 = lp + o.l_b3;
+            a.bo = lp + o.l_bo;
+            a.hvec = ws + w.hvec + (size_t)l * B * C;
+            a.dvec = ws + w.dvec + (size_t)l * B * C;
+            a.h_save = save ? ws + w.h + (size_t)l * w.act_stride : nullptr;
+            a.g_save = save ? ws + w.g + (size_t)l * w.act_stride : nullptr;
+            a.sig_save = save ? ws + w.sig + (size_t)l * w.act_stride : nullptr;
+            a.tnh_save = save ? ws + w.tnh + (size_t)l * w.act_stride : nullptr;
+            a.L = L;
+            a.tiles_per_b = mg_cdiv(L, RB_NT);
+            a.first = (l == 0);
+            dim3 grid((unsigned)(a.tiles_per_b * B));
+            prof_mark(st, 0);
+            if (save) {
+                if (vec4) hipLaunchKernelGGL((resblock_fused_kernel<true, true>), grid, dim3(512), 0, st, a);
+                else hipLaunchKernelGGL((resblock_fused_kernel<false, true>), grid, dim3(512), 0, st, a);
+            } else {
+                if (vec4) hipLaunchKernelGGL((resblock_fused_kernel<true, false>), grid, dim3(512), 0, st, a);
+                else hipLaunchKernelGGL((resblock_fused_kernel<false, false>), grid, dim3(512), 0, st, a);
+            }
+            prof_mark(st, 1);
+            MG_LAUNCH_CHECK();
+            float *tmp = xa;
+            xa = xb;
+            xb = tmp;
+        }
+    } else
     for (int l = 0; l < NL; ++l) {
         const float *lp = lay0 + (size_t)l * o.layer_stride;
         float *hbuf = ws + w.h + (size_t)l * w.act_stride;

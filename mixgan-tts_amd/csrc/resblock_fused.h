@@ -1,0 +1,273 @@
+// One gated residual layer of the Denoiser (model/blocks.py:1157-1176) as ONE kernel, gfx950.
+//
+//   h = Wc cond + bc + x + (Wd s [+ Wp spk])                     GEMM 1   M=256  K=256
+//   g = sigmoid(z[:C]) * tanh(z[C:]),  z = W3 (*) h + b3          GEMM 2   M=512  K=768 (k=3)
+//   o = Wo g + bo;  x' = (o[:C] + x + Wd s)/sqrt2;  skip += o[C:] GEMM 3   M=512  K=256
+//
+// A workgroup (512 threads = 8 waves, 2 per SIMD) owns 64 frames of one utterance and keeps the
+// whole 256-channel column of that tile in LDS across the three GEMMs, so h and g never touch
+// HBM: per frame and layer the kernel reads cond, x, skip and writes x', skip (5 KB instead of
+// the 10 KB of the three-launch form).  The k=3 convolution needs h on a 1-frame halo each side;
+// GEMM 1 therefore produces 66 columns (the third 32-column MFMA block carries 2 useful columns:
+// 5 % extra MFMAs per layer, no inter-workgroup exchange).  x is double-buffered across layers
+// (x_in -> x_out) because neighbouring tiles read each other's halo frames.
+//
+// LDS (143,488 B of the CU's 160 KiB, one workgroup per CU):
+//   condT [256][72] (+32 pad)  col j <-> frame l0-4+j   (16-byte aligned rows for float4 staging)
+//   hT    [256][68]            col j <-> frame l0-1+j
+//   gT    [256][64]            aliases condT once GEMM 1 is done
+// MFMA operands: weights stream global/L2 -> VGPR in fragment order (conv_mfma.h packing);
+// activations come from the LDS tiles with one conflict-free ds_read_b32 per 32x32x2 MFMA; the
+// tap shift of the k=3 conv is an address offset into hT.
+//
+// The epilogue addends of GEMM 3 (x, skip, biases, step vector) are loaded before its k-loop and
+// consumed after it, so their latency hides behind 512 MFMAs per wave; GEMM 1's accumulators
+// are initialised with x + bias + step vector while the cond tile is being staged.
+#pragma once
+#include "common.h"
+
+#define RB_C 256
+#define RB_NT 64
+#define RB_RSC 72
+#define RB_RSH 68
+#define RB_RSG 64
+#define RB_COND_FLOATS (RB_C * RB_RSC + 32)
+#define RB_H_FLOATS (RB_C * RB_RSH)
+#define RB_LDS_FLOATS (RB_COND_FLOATS + RB_H_FLOATS)
+
+struct ResArgs {
+    const float *cond;  // [B, 256, L]
+    const float *x_in;  // [B, 256, L]
+    float *x_out;       // [B, 256, L]
+    float *skip;        // [B, 256, L] running sum
+    const float *wc;    // packed PLAIN [256 rows, K=256]
+    const float *w3;    // packed GATE  [512 rows, K=256 x 3 taps]
+    const float *wo;    // packed PLAIN [512 rows, K=256]
+    const float *bc, *b3, *bo;
+    const float *hvec;  // [B, 256]  Wd s (+ Wp spk): enters h only
+    const float *dvec;  // [B, 256]  Wd s: enters the residual
+    float *h_save, *sig_save, *tnh_save, *g_save;  // [B, 256, L] each, SAVE only
+    int L, tiles_per_b, first;
+};
+
+// k-loop of one GEMM phase.  Rows of the B tile are channels; `bcol` is this lane's first column.
+template <int NMB, int NNB, int KW, int RS>
+__device__ __forceinline__ void rb_mfma_loop(f32x16 (&acc)[NMB][NNB], const f32x4 *ap0, int qstride_mb,
+                                             const float *__restrict__ tile, int bcol)
+{
+    constexpr int QC = KW * 4;       // k-groups per 32-channel chunk
+    constexpr int Q = 8 * QC;        // RB_C / 32 chunks
+    const f32x4 *ap[NMB];
+#pragma unroll
+    for (int i = 0; i < NMB; ++i) ap[i] = ap0 + (size_t)i * qstride_mb;
+    f32x4 a_cur[NMB], a_nxt[NMB];
+#pragma unroll
+    for (int i = 0; i < NMB; ++i) a_cur[i] = ap[i][0];
+    int q = 0;
+    for (int chunk = 0; chunk < 8; ++chunk) {
+        const float *T = tile + chunk * 32 * RS + bcol;
+#pragma unroll
+        for (int tap = 0; tap < KW; ++tap) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                ++q;
+                const int qn = q < Q ? q : Q - 1;
+#ifdef RB_ABLATE_A  // diagnostic builds only (tools/ubench): drop the weight stream
+#pragma unroll
+                for (int i = 0; i < NMB; ++i) a_nxt[i] = a_cur[i];
+                (void)qn;
+#else
+#pragma unroll
+                for (int i = 0; i < NMB; ++i) a_nxt[i] = ap[i][(size_t)qn * 64];
+#endif
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float bv[NNB];
+#pragma unroll
+#ifdef RB_ABLATE_B  // diagnostic builds only: drop the LDS operand reads
+                    for (int j = 0; j < NNB; ++j) bv[j] = a_cur[0][(e + j) & 3];
+#else
+                    for (int j = 0; j < NNB; ++j) bv[j] = T[(g * 8 + 2 * e) * RS + 32 * j + tap];
+#endif
+#pragma unroll
+                    for (int i = 0; i < NMB; ++i)
+#pragma unroll
+                        for (int j = 0; j < NNB; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][e], bv[j], acc[i][j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < NMB; ++i) a_cur[i] = a_nxt[i];
+            }
+        }
+    }
+}
+
+template <bool VEC4, bool SAVE>
+__global__ __launch_bounds__(512, 2) void resblock_fused_kernel(ResArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float lds[RB_LDS_FLOATS];
+    float *condT = lds;
+    float *hT = lds + RB_COND_FLOATS;
+    float *gT = lds;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int hh = lane >> 5, c32 = lane & 31;
+    const int b = blockIdx.x / a.tiles_per_b;
+    const int l0 = (blockIdx.x - b * a.tiles_per_b) * RB_NT;
+    const int L = a.L;
+    const size_t bbase = (size_t)b * RB_C * L;
+
+    // ---------------------------------------------------------------- stage cond tile -> LDS
+    {
+        const float *cb = a.cond + bbase;
+        if (VEC4) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int idx = tid + k * 512;  // 256 rows x 18 float4
+                const int row = idx / 18, c4 = idx - row * 18;
+                const int f0 = l0 - 4 + 4 * c4;
+                // unconditional load from a clamped address + select: a branch around each load would
+                // serialise them behind vmcnt(0) (cdna_hip_programming.md, "three .s-level traps" (c))
+                const bool ok = f0 >= 0 && f0 < L;
+                const int fc = min(max(f0, 0), L - 4);
+                f32x4 v = *reinterpret_cast<const f32x4 *>(cb + (size_t)row * L + fc);
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4 *>(condT + row * RB_RSC + 4 * c4) = ok ? v : z;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 33; ++k) {  // 256 rows x 66 frames = 33 x 512
+                const int idx = tid + k * 512;
+                const int row = idx / 66, cc = idx - row * 66;
+                const int f = l0 - 1 + cc;
+                const float v = cb[(size_t)row * L + min(max(f, 0), L - 1)];
+                condT[row * RB_RSC + 3 + cc] = (f >= 0 && f < L) ? v : 0.f;
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- GEMM 1: h (66 columns)
+    f32x16 acc1[1][3];
+    {
+        const float *xb = a.x_in + bbase;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = w * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
+            const float add = a.bc[row] + a.hvec[(size_t)b * RB_C + row];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int f = l0 - 1 + 32 * j + c32;
+                const bool ok = f >= 0 && f < L && (j < 2 || c32 < 2);
+                const float v = xb[(size_t)row * L + min(max(f, 0), L - 1)];
+                acc1[0][j][r] = ok ? v + add : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    rb_mfma_loop<1, 3, 1, RB_RSC>(acc1, reinterpret_cast<const f32x4 *>(a.wc) + (size_t)w * 32 * 64 + lane, 0,
+                                  condT + hh * RB_RSC, 3 + c32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = w * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int col = 32 * j + c32;
+            if (j < 2 || c32 < 2) {
+                const int f = l0 - 1 + col;
+                const bool ok = f >= 0 && f < L;  // zero padding of the k=3 conv applies to h
+                const float v = ok ? acc1[0][j][r] : 0.f;
+                hT[row * RB_RSH + col] = v;
+                if (SAVE && ok && col >= 1 && col <= RB_NT) a.h_save[bbase + (size_t)row * L + f] = v;
+            }
+        }
+    }
+
+    __syncthreads();  // hT complete; condT free
+
+    // ---------------------------------------------------------------- GEMM 2: z = W3 (*) h, gate
+    f32x16 acc2[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+    rb_mfma_loop<2, 2, 3, RB_RSH>(acc2, reinterpret_cast<const f32x4 *>(a.w3) + (size_t)(2 * w) * 96 * 64 + lane, 96 * 64,
+                                  hT + hh * RB_RSH, c32);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ch = w * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
+        const float bg = a.b3[ch], bf = a.b3[RB_C + ch];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float s = mg_sigmoid(acc2[0][j][r] + bg);
+            const float t = mg_tanh(acc2[1][j][r] + bf);
+            const int col = 32 * j + c32;
+            gT[ch * RB_RSG + col] = s * t;
+            if (SAVE) {
+                const int f = l0 + col;
+                if (f < L) {
+                    const size_t o = bbase + (size_t)ch * L + f;
+                    a.sig_save[o] = s;
+                    a.tnh_save[o] = t;
+                    a.g_save[o] = s * t;
+                }
+            }
+        }
+    }
+    // ---------------------------------------------------------------- GEMM 3's addends: loaded here (acc2 is dead), consumed after GEMM 3
+    // wave w owns rows 64w..64w+63 of o: w < 4 -> x rows, w >= 4 -> skip rows
+    f32x16 add3[2][2];
+    {
+        const bool xrows = w < 4;
+        const float *src = xrows ? a.x_in + bbase : a.skip + bbase;
+        const float *vec = a.dvec + (size_t)b * RB_C;
+        const float use_src = (xrows || !a.first) ? 1.f : 0.f;  // layer 0 starts the skip sum
+        const float use_vec = xrows ? 1.f : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = w * 64 + i * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
+                const int ch = row & (RB_C - 1);
+                const float add = a.bo[row] + use_vec * vec[ch];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int f = min(l0 + 32 * j + c32, L - 1);  // frames >= L are never stored
+                    add3[i][j][r] = add + use_src * src[(size_t)ch * L + f];
+                }
+            }
+        }
+    }
+    __syncthreads();  // gT complete
+
+    // ---------------------------------------------------------------- GEMM 3: o = Wo g, residual / skip
+    f32x16 acc3[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc3[i][j][r] = 0.f;
+    rb_mfma_loop<2, 2, 1, RB_RSG>(acc3, reinterpret_cast<const f32x4 *>(a.wo) + (size_t)(2 * w) * 32 * 64 + lane, 32 * 64,
+                                  gT + hh * RB_RSG, c32);
+    {
+        const bool xrows = w < 4;
+        float *dst = xrows ? a.x_out + bbase : a.skip + bbase;
+        const float sc = xrows ? 0.70710678118654752440f : 1.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = (w * 64 + i * 32 + 8 * (r >> 2) + 4 * hh + (r & 3)) & (RB_C - 1);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int f = l0 + 32 * j + c32;
+                    if (f < L) dst[(size_t)ch * L + f] = (acc3[i][j][r] + add3[i][j][r]) * sc;
+                }
+            }
+        }
+    }
+}
