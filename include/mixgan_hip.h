@@ -66,6 +66,31 @@ int mg_conv1d_fwd(const float *in, const float *in_vec, const float *packed, con
                   const float *add, float *out, int B, int Ci, int Lin, int Co, int Lout, int K,
                   int stride, int pad, int act, float alpha, int accumulate, void *stream);
 
+/* As mg_conv_pack, but writes k-groups [q0, q0+Q) of a packed buffer holding Qtot k-groups per
+ * 32-row block: concatenates weights that share their rows along the reduction axis. */
+int mg_conv_pack_at(const float *w, float *packed, int Co, int Ci, int K, int mode, int q0, int Qtot,
+                    void *stream);
+
+/* Weight gradient of the same convolution (autograd of nn.Conv1d / nn.Linear weights):
+ *   dw[co,ci,k] (+)= alpha * sum_{b,l} dy[b,co,l] * (x[b,ci,l*stride+k-pad] + x_vec[b,ci])
+ * dy [B,Co,Ldy], x [B,Ci,Lx], dw [Co,Ci,K]; scratch: mg_conv1d_wgrad_scratch_floats() floats
+ * (zeroed by the call; partial tiles are combined there with fp32 atomics, so the summation order
+ * over frames is not fixed run to run). */
+size_t mg_conv1d_wgrad_scratch_floats(int Co, int Ci, int K);
+int mg_conv1d_wgrad(const float *dy, const float *x, const float *x_vec, float *dw, float *scratch,
+                    int B, int Co, int Ci, int Ldy, int Lx, int K, int stride, int pad, float alpha,
+                    int accumulate, void *stream);
+
+/* Same with explicit batch strides (floats; 0 = dense) so dy / x may be channel slices of wider tensors. */
+int mg_conv1d_wgrad_strided(const float *dy, long dy_bs, const float *x, long x_bs, const float *x_vec,
+                            float *dw, float *scratch, int B, int Co, int Ci, int Ldy, int Lx, int K,
+                            int stride, int pad, float alpha, int accumulate, void *stream);
+
+/* Row sums of in [B,R,L] (batch stride in_bs floats, 0 = dense): bias gradients and per-sample
+ * channel sums.  out_r[r] (+)= alpha*sum_{b,l} (may be NULL); out_br[b,r] = alpha*sum_l (may be NULL). */
+int mg_rowsum(const float *in, long in_bs, int B, int R, int L, float *out_r, float *out_br,
+              float alpha, int accumulate, void *stream);
+
 /* ------------------------------------------------------------------ diffusion algebra (HBM-bound)
  * Schedule tables are the fp32 buffers of GaussianDiffusion (model/diffusion.py:60-83). */
 
@@ -129,11 +154,12 @@ typedef struct {
 #define MG_DEN_HEAD_PTRS 8
 #define MG_DEN_LAYER_PTRS 9
 
-size_t mg_denoiser_packed_floats(const mg_denoiser_dims *d);
+/* with_backward != 0 also packs the transposed (data-gradient) forms mg_denoiser_bwd consumes. */
+size_t mg_denoiser_packed_floats(const mg_denoiser_dims *d, int with_backward);
 /* freq: the C/2 step-embedding frequencies exp(-i ln(1e4)/(C/2-1)) (model/blocks.py:909-910),
  * computed by the host exactly as the reference does and cached in the packed blob. */
 int mg_denoiser_pack(const mg_denoiser_dims *d, const float *const *weights, const float *freq,
-                     float *packed, void *stream);
+                     float *packed, int with_backward, void *stream);
 /* Workspace (floats) for a forward of batch B, L frames.  save_for_backward additionally keeps the
  * per-layer activations that mg_denoiser_bwd consumes. */
 size_t mg_denoiser_workspace_floats(const mg_denoiser_dims *d, int B, int L, int save_for_backward);
@@ -144,6 +170,20 @@ int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, const float 
                     const int64_t *t, const float *cond, const float *spk, float *out,
                     float *workspace, size_t workspace_floats, int B, int L, int save_for_backward,
                     void *stream);
+
+/* Backward of Denoiser.forward (what torch.autograd does for the reference).  `workspace` is the
+ * forward's workspace of a save_for_backward call on the same inputs; `bwd_workspace` has
+ * mg_denoiser_bwd_workspace_floats() floats.  g_out [B, M, L] is dL/d(out).
+ * grads: pointer table in the order of mg_denoiser_pack's weight table; every non-NULL entry
+ * receives dL/dW (overwritten, not accumulated).  The per-layer entries j=2 (diffusion_projection),
+ * j=3/j=4 (conditioner_projection weight/bias) and j=7 (speaker_projection) must be slices of
+ * one contiguous [n_layers, ...] buffer each (they are produced by one batched GEMM).
+ * d_x_t [B,M,L], d_cond [B,H,L], d_spk [B,H] may be NULL when not needed. */
+size_t mg_denoiser_bwd_workspace_floats(const mg_denoiser_dims *d, int B, int L);
+int mg_denoiser_bwd(const mg_denoiser_dims *d, const float *packed, const float *g_out,
+                    const float *x_t, const float *cond, const float *spk, float *workspace,
+                    float *bwd_workspace, size_t bwd_workspace_floats, float *const *grads,
+                    float *d_x_t, float *d_cond, float *d_spk, int B, int L, void *stream);
 
 /* ------------------------------------------------------------------ measurement hooks (bench.py)
  * While a session is open, mg_denoiser_fwd brackets each launch of its dominant kernel (the k=3

@@ -10,9 +10,11 @@ _LIB = None
 
 EXPORTS = (
     "mg_version", "mg_error_string",
-    "mg_conv_packed_floats", "mg_conv_pack", "mg_conv1d_fwd",
+    "mg_conv_packed_floats", "mg_conv_pack", "mg_conv_pack_at", "mg_conv1d_fwd",
+    "mg_conv1d_wgrad_scratch_floats", "mg_conv1d_wgrad", "mg_conv1d_wgrad_strided", "mg_rowsum",
     "mg_diffuse_fwd", "mg_posterior_sample_fwd", "mg_posterior_sample_bwd", "mg_spec_affine", "mg_transpose_bml",
     "mg_denoiser_packed_floats", "mg_denoiser_pack", "mg_denoiser_workspace_floats", "mg_denoiser_fwd",
+    "mg_denoiser_bwd_workspace_floats", "mg_denoiser_bwd",
     "mg_profile_begin", "mg_profile_end",
 )
 
@@ -68,8 +70,15 @@ def _declare(L):
         "mg_transpose_bml": (i, [vp] * 5 + [i, i, i, i, i, vp]),
         "mg_posterior_sample_bwd": (i, [vp] * 7 + [i, i, i, i, i, vp]),
         "mg_spec_affine": (i, [vp, vp, vp, vp, i, sz, i, vp]),
-        "mg_denoiser_packed_floats": (sz, [dp]),
-        "mg_denoiser_pack": (i, [dp, vp, vp, vp, vp]),
+        "mg_conv_pack_at": (i, [vp, vp, i, i, i, i, i, i, vp]),
+        "mg_conv1d_wgrad_scratch_floats": (sz, [i, i, i]),
+        "mg_conv1d_wgrad": (i, [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, i, vp]),
+        "mg_conv1d_wgrad_strided": (i, [vp, ctypes.c_long, vp, ctypes.c_long, vp, vp, vp, i, i, i, i, i, i, i, i, f, i, vp]),
+        "mg_rowsum": (i, [vp, ctypes.c_long, i, i, i, vp, vp, f, i, vp]),
+        "mg_denoiser_packed_floats": (sz, [dp, i]),
+        "mg_denoiser_pack": (i, [dp, vp, vp, vp, i, vp]),
+        "mg_denoiser_bwd_workspace_floats": (sz, [dp, i, i]),
+        "mg_denoiser_bwd": (i, [dp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, i, i, vp]),
         "mg_denoiser_workspace_floats": (sz, [dp, i, i, i]),
         "mg_denoiser_fwd": (i, [dp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, vp]),
         "mg_profile_begin": (i, [i]),

@@ -61,6 +61,7 @@ class DenoiserFn(torch.autograd.Function):
         _require_cuda(x, cond)
         out = module.run(x, t, cond, spk, save=True)
         ctx.module = module
+        ctx.gen = module._save_gen
         ctx.save_for_backward(x, t, cond, spk if spk is not None else x.new_empty(0))
         ctx.has_spk = spk is not None
         return out
@@ -68,8 +69,10 @@ class DenoiserFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, t, cond, spk = ctx.saved_tensors
-        return ctx.module.run_backward(g.contiguous(), x, t, cond, spk if ctx.has_spk else None,
-                                       ctx.needs_input_grad)
+        need = ctx.needs_input_grad
+        d_x, d_cond, d_spk, pg = ctx.module.run_backward(g.contiguous(), x, t, cond, spk if ctx.has_spk else None,
+                                                         ctx.gen, need[1], need[3], need[4])
+        return (None, d_x, None, d_cond, d_spk) + tuple(pg)
 
 
 def denoise_and_posterior(diff, x_t, t, cond_t, spk, post_noise, keep, clip, coarse_mel):

@@ -1,11 +1,12 @@
 // Weight packing + the generic mg_conv1d_fwd entry point.
 #include "conv_mfma.h"
+#include "wgrad_mfma.h"
 
 // ---------------------------------------------------------------------------------------------
 // pack: [Co, Ci, K] fp32 -> Wp[mb][q][lane][e]  (layout: conv_mfma.h header)
 // ---------------------------------------------------------------------------------------------
 __global__ void pack_conv_kernel(const float *__restrict__ w, float *__restrict__ wp, int Co, int Ci, int K, int CK,
-                                 int CiP, int MB, int mode)
+                                 int CiP, int MB, int mode, int q0, int Qtot)
 {
     const int Q = CiP * K / 8;
     const size_t total = (size_t)MB * Q * 256;
@@ -33,7 +34,7 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, float *__restrict_
             const int row = mb * 32 + r;
             if (row < Ci && ci < Co) v = w[((size_t)ci * Ci + row) * K + (K - 1 - tap)];
         }
-        wp[idx] = v;
+        wp[(((size_t)mb * Qtot + q0 + q) << 8) + (idx & 255)] = v;
     }
 }
 
@@ -66,19 +67,33 @@ extern "C" size_t mg_conv_packed_floats(int Co, int Ci, int K, int mode)
     return (size_t)MB * (CiP * K / 8) * 256;
 }
 
-extern "C" int mg_conv_pack(const float *w, float *packed, int Co, int Ci, int K, int mode, void *stream)
+// Packs one [Co, Ci, K] weight as k-groups [q0, q0 + Q) of a packed buffer that holds Qtot k-groups
+// per 32-row block: lets several weights that share their rows be concatenated along the
+// reduction axis (e.g. all 20 conditioner projections as one K = 20*256 data-gradient GEMM).
+extern "C" int mg_conv_pack_at(const float *w, float *packed, int Co, int Ci, int K, int mode, int q0, int Qtot,
+                               void *stream)
 {
     if (!w || !packed) return MG_ERR_ARG;
     int Mrows, Kin, MB;
     MG_TRY(pack_dims(Co, Ci, K, mode, &Mrows, &Kin, &MB));
     const int CK = mg_conv_ck(K);
     const int CiP = mg_round_up(Kin, CK);
-    const size_t total = (size_t)MB * (CiP * K / 8) * 256;
+    const int Q = CiP * K / 8;
+    if (q0 < 0 || q0 + Q > Qtot) return MG_ERR_SHAPE;
+    const size_t total = (size_t)MB * Q * 256;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_conv_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Co, Ci, K, CK, CiP,
-                       MB, mode);
+                       MB, mode, q0, Qtot);
     MG_LAUNCH_CHECK();
     return MG_OK;
+}
+
+extern "C" int mg_conv_pack(const float *w, float *packed, int Co, int Ci, int K, int mode, void *stream)
+{
+    int Mrows, Kin, MB;
+    MG_TRY(pack_dims(Co, Ci, K, mode, &Mrows, &Kin, &MB));
+    const int Q = mg_round_up(Kin, mg_conv_ck(K)) * K / 8;
+    return mg_conv_pack_at(w, packed, Co, Ci, K, mode, 0, Q, stream);
 }
 
 extern "C" int mg_conv1d_fwd(const float *in, const float *in_vec, const float *packed, const float *bias,
@@ -90,6 +105,65 @@ extern "C" int mg_conv1d_fwd(const float *in, const float *in_vec, const float *
     if (B <= 0 || Ci <= 0 || Co <= 0 || Lin <= 0 || Lout <= 0 || pad < 0) return MG_ERR_SHAPE;
     if ((Lin + 2 * pad - K) / stride + 1 < Lout) return MG_ERR_SHAPE;  // would read past the padded input
     ConvShape s{B, Ci, Lin, Lout, K, stride, pad, Co, 0, 0};
-    EpiBiasAct::Params ep{out, bias, add, alpha, Co, act, accumulate};
+    EpiBiasAct::Params ep{out, bias, add, alpha, Co, act, accumulate, 0, nullptr};
     return conv_launch<EpiBiasAct>(s, in, in_vec, packed, ep, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient + row sums (bias gradients, per-sample channel sums)
+// ---------------------------------------------------------------------------------------------
+extern "C" size_t mg_conv1d_wgrad_scratch_floats(int Co, int Ci, int K) { return (size_t)Co * Ci * K; }
+
+extern "C" int mg_conv1d_wgrad_strided(const float *dy, long dy_bs, const float *x, long x_bs, const float *x_vec,
+                                       float *dw, float *scratch, int B, int Co, int Ci, int Ldy, int Lx, int K,
+                                       int stride, int pad, float alpha, int accumulate, void *stream)
+{
+    if (!dy || !x || !dw || !scratch) return MG_ERR_ARG;
+    if (stride < 1 || pad < 0) return MG_ERR_SHAPE;
+    WgradShape s{B, Co, Ci, Ldy, Lx, K, stride, pad, dy_bs, x_bs};
+    return wgrad_launch(s, dy, x, x_vec, dw, scratch, alpha, accumulate, (hipStream_t)stream);
+}
+
+extern "C" int mg_conv1d_wgrad(const float *dy, const float *x, const float *x_vec, float *dw, float *scratch, int B,
+                               int Co, int Ci, int Ldy, int Lx, int K, int stride, int pad, float alpha,
+                               int accumulate, void *stream)
+{
+    return mg_conv1d_wgrad_strided(dy, 0, x, 0, x_vec, dw, scratch, B, Co, Ci, Ldy, Lx, K, stride, pad, alpha, accumulate,
+                                   stream);
+}
+
+// in [B, R, L] (batch stride in_bs, 0 -> R*L).  out_r[r] (+)= alpha * sum_{b,l};  out_br[b*R + r] = alpha * sum_l.
+__global__ __launch_bounds__(256) void rowsum_kernel(const float *__restrict__ in, long in_bs, int B, int R, int L,
+                                                     float *__restrict__ out_r, float *__restrict__ out_br,
+                                                     float alpha, int accumulate)
+{
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float tot = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float *p = in + (size_t)b * in_bs + (size_t)r * L;
+        float v = 0.f;
+        for (int l = threadIdx.x; l < L; l += 256) v += p[l];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        const float s = red[0] + red[1] + red[2] + red[3];
+        if (out_br && threadIdx.x == 0) out_br[(size_t)b * R + r] = alpha * s;
+        tot += s;
+    }
+    if (out_r && threadIdx.x == 0) out_r[r] = accumulate ? out_r[r] + alpha * tot : alpha * tot;
+}
+
+extern "C" int mg_rowsum(const float *in, long in_bs, int B, int R, int L, float *out_r, float *out_br, float alpha,
+                         int accumulate, void *stream)
+{
+    if (!in || (!out_r && !out_br)) return MG_ERR_ARG;
+    if (B <= 0 || R <= 0 || L <= 0) return MG_ERR_SHAPE;
+    hipLaunchKernelGGL(rowsum_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, in, in_bs ? in_bs : (long)R * L, B, R, L,
+                       out_r, out_br, alpha, accumulate);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
 }

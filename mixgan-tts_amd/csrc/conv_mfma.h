@@ -53,6 +53,8 @@ struct EpiBiasAct {
         int Co;
         int act;           // MG_ACT_*
         int accumulate;    // out += result
+        long out_bs;       // batch stride of out (0 -> Co*Lout): lets the output be a channel slice
+        const float *mask; // optional [B, Co, Lout] dense: result *= (mask > 0)   (ReLU backward)
     };
     template <int WM>
     static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][2], int b, int mrow0, int l0w,
@@ -66,8 +68,10 @@ struct EpiBiasAct {
                 const int row = mrow0 + i * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
                 if (row >= p.Co) continue;
                 const float bv = p.bias ? p.bias[row] : 0.f;
-                float *orow = p.out + ((size_t)b * p.Co + row) * Lout;
-                const float *arow = p.add ? p.add + ((size_t)b * p.Co + row) * Lout : nullptr;
+                const size_t dense = ((size_t)b * p.Co + row) * Lout;
+                float *orow = p.out_bs ? p.out + (size_t)b * p.out_bs + (size_t)row * Lout : p.out + dense;
+                const float *arow = p.add ? p.add + dense : nullptr;
+                const float *mrow = p.mask ? p.mask + dense : nullptr;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int l = l0w + j * 32 + c;
@@ -80,6 +84,7 @@ struct EpiBiasAct {
                         default: break;
                         }
                         if (arow) v += arow[l];
+                        if (mrow) v = mrow[l] > 0.f ? v : 0.f;
                         if (p.accumulate) v += orow[l];
                         orow[l] = v;
                     }

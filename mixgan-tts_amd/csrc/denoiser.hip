@@ -8,7 +8,7 @@
 //   (3) o = Wo g + bo;  x <- (o[:C] + x + Wd s)/sqrt2;  skip += o[C:]     k=1, EpiResSkip
 // The 20 skip tensors are never materialised (the reference stacks them, model/modules.py:441);
 // a running fp32 sum is kept instead.
-#include "conv_mfma.h"
+#include "denoiser_common.h"
 #include "resblock_fused.h"
 #include <cstdlib>
 
@@ -129,130 +129,11 @@ struct EpiResSkip {
     }
 };
 
-// ------------------------------------------------------------------------------------------ small linears
-// step embedding (model/blocks.py:906-913): emb[b] = [sin(t f_i) | cos(t f_i)], f from the host table
-__global__ void step_embed_kernel(const int64_t *__restrict__ t, const float *__restrict__ freq,
-                                  float *__restrict__ emb, int B, int C)
-{
-    const int half = C / 2;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * half) return;
-    const int b = idx / half, i = idx - b * half;
-    const float ang = (float)t[b] * freq[i];
-    emb[(size_t)b * C + i] = sinf(ang);
-    emb[(size_t)b * C + half + i] = cosf(ang);
-}
-
-// out[z][b][j] = act(sum_i W[z][j][i] * in[b][i]) (+ add[z][b][j]);  one wave per output row j.
-template <int BC>
-__global__ __launch_bounds__(256) void small_linear_kernel(const float *__restrict__ W, long w_zs,
-                                                           const float *__restrict__ in, float *__restrict__ out,
-                                                           long out_zs, const float *__restrict__ add, long add_zs,
-                                                           int B, int N, int K, int mish)
-{
-    const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int b0 = blockIdx.y * BC;
-    const int z = blockIdx.z;
-    if (j >= N) return;
-    const float *w = W + (size_t)z * w_zs + (size_t)j * K;
-    float acc[BC];
-#pragma unroll
-    for (int b = 0; b < BC; ++b) acc[b] = 0.f;
-    for (int i = lane; i < K; i += 64) {
-        const float wv = w[i];
-#pragma unroll
-        for (int b = 0; b < BC; ++b)
-            if (b0 + b < B) acc[b] = fmaf(wv, in[(size_t)(b0 + b) * K + i], acc[b]);
-    }
-#pragma unroll
-    for (int b = 0; b < BC; ++b) {
-        float v = acc[b];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0 && b0 + b < B) {
-            if (mish) {  // x * tanh(softplus(x)), softplus threshold 20 (F.softplus defaults)
-                const float sp = v > 20.f ? v : log1pf(expf(v));
-                v = v * tanhf(sp);
-            }
-            const size_t o = (size_t)z * out_zs + (size_t)(b0 + b) * N + j;
-            if (add) v += add[(size_t)z * add_zs + (size_t)(b0 + b) * N + j];
-            out[o] = v;
-        }
-    }
-}
-
-static int small_linear(const float *W, long w_zs, const float *in, float *out, long out_zs, const float *add,
-                        long add_zs, int B, int N, int K, int Z, int mish, hipStream_t st)
-{
-    constexpr int BC = 8;
-    dim3 grid(mg_cdiv(N, 4), mg_cdiv(B, BC), Z);
-    hipLaunchKernelGGL(small_linear_kernel<BC>, grid, dim3(256), 0, st, W, w_zs, in, out, out_zs, add, add_zs, B, N, K,
-                       mish);
-    MG_LAUNCH_CHECK();
-    return MG_OK;
-}
-
-// ------------------------------------------------------------------------------------------ packed blob
-struct DenLayout {
-    // offsets in floats into the packed blob
-    size_t freq, in_w, in_b, mlp0, mlp2, skip_w, skip_b, out_w, out_b, layers, layer_stride;
-    size_t l_w3, l_b3, l_wd, l_wc, l_bc, l_wo, l_bo, l_wp;  // offsets inside a layer record
-    size_t total;
-};
-
-static DenLayout den_layout(const mg_denoiser_dims *d)
-{
-    const int C = d->channels, H = d->cond_channels, M = d->mel_bins;
-    DenLayout o;
-    size_t p = 0;
-    auto take = [&](size_t n) {
-        size_t at = p;
-        p += mg_align_up(n, 64);
-        return at;
-    };
-    o.freq = take(C / 2);
-    o.in_w = take(mg_conv_packed_floats(C, M, 1, MG_PACK_PLAIN));
-    o.in_b = take(C);
-    o.mlp0 = take((size_t)4 * C * C);
-    o.mlp2 = take((size_t)4 * C * C);
-    o.skip_w = take(mg_conv_packed_floats(C, C, 1, MG_PACK_PLAIN));
-    o.skip_b = take(C);
-    o.out_w = take(mg_conv_packed_floats(M, C, 1, MG_PACK_PLAIN));
-    o.out_b = take(M);
-    o.layers = p;
-    size_t q = 0;
-    auto ltake = [&](size_t n) {
-        size_t at = q;
-        q += mg_align_up(n, 64);
-        return at;
-    };
-    o.l_wc = ltake(mg_conv_packed_floats(C, H, 1, MG_PACK_PLAIN));
-    o.l_w3 = ltake(mg_conv_packed_floats(2 * C, C, 3, MG_PACK_GATE));
-    o.l_wo = ltake(mg_conv_packed_floats(2 * C, C, 1, MG_PACK_PLAIN));
-    o.l_bc = ltake(C);
-    o.l_b3 = ltake(2 * C);
-    o.l_bo = ltake(2 * C);
-    o.l_wd = ltake((size_t)C * C);
-    o.l_wp = ltake(d->multi_speaker ? (size_t)C * H : 0);
-    o.layer_stride = q;
-    o.total = p + q * d->n_layers;
-    return o;
-}
-
-static int den_check(const mg_denoiser_dims *d)
-{
-    if (!d) return MG_ERR_ARG;
-    if (d->n_layers <= 0 || d->n_layers > 256 || d->channels <= 0 || d->channels % 64 || d->cond_channels <= 0 ||
-        d->mel_bins <= 0)
-        return MG_ERR_SHAPE;
-    return MG_OK;
-}
-
-extern "C" size_t mg_denoiser_packed_floats(const mg_denoiser_dims *d)
+// ------------------------------------------------------------------------------------------ packing
+extern "C" size_t mg_denoiser_packed_floats(const mg_denoiser_dims *d, int with_backward)
 {
     if (den_check(d) != MG_OK) return 0;
-    return den_layout(d).total;
+    return den_layout(d, with_backward).total;
 }
 
 static int copy_d2d(float *dst, const float *src, size_t n, hipStream_t st)
@@ -263,13 +144,13 @@ static int copy_d2d(float *dst, const float *src, size_t n, hipStream_t st)
 }
 
 extern "C" int mg_denoiser_pack(const mg_denoiser_dims *d, const float *const *w, const float *freq, float *packed,
-                                void *stream)
+                                int with_backward, void *stream)
 {
     MG_TRY(den_check(d));
     if (!w || !packed || !freq) return MG_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int C = d->channels, H = d->cond_channels, M = d->mel_bins;
-    const DenLayout o = den_layout(d);
+    const DenLayout o = den_layout(d, with_backward);
     for (int i = 0; i < MG_DEN_HEAD_PTRS; ++i)
         if (!w[i]) return MG_ERR_ARG;
     MG_TRY(copy_d2d(packed + o.freq, freq, C / 2, st));
@@ -295,42 +176,21 @@ extern "C" int mg_denoiser_pack(const mg_denoiser_dims *d, const float *const *w
         MG_TRY(copy_d2d(lp + o.l_bo, lw[6], 2 * C, st));
         if (d->multi_speaker) MG_TRY(copy_d2d(lp + o.l_wp, lw[7], (size_t)C * H, st));
     }
+    if (with_backward) {
+        // data-gradient (transposed, tap-flipped) packs for mg_denoiser_bwd
+        MG_TRY(mg_conv_pack(w[0], packed + o.in_wT, C, M, 1, MG_PACK_DGRAD, stream));
+        MG_TRY(mg_conv_pack(w[4], packed + o.skip_wT, C, C, 1, MG_PACK_DGRAD, stream));
+        MG_TRY(mg_conv_pack(w[6], packed + o.out_wT, M, C, 1, MG_PACK_DGRAD, stream));
+        const int Qtot = d->n_layers * C / 8;
+        for (int l = 0; l < d->n_layers; ++l) {
+            const float *const *lw = w + MG_DEN_HEAD_PTRS + (size_t)l * MG_DEN_LAYER_PTRS;
+            float *bp = packed + o.blayers + (size_t)l * o.blayer_stride;
+            MG_TRY(mg_conv_pack_at(lw[3], packed + o.wc_allT, C, H, 1, MG_PACK_DGRAD, l * (C / 8), Qtot, stream));
+            MG_TRY(mg_conv_pack(lw[0], bp + o.bl_w3T, 2 * C, C, 3, MG_PACK_DGRAD, stream));
+            MG_TRY(mg_conv_pack(lw[5], bp + o.bl_woT, 2 * C, C, 1, MG_PACK_DGRAD, stream));
+        }
+    }
     return MG_OK;
-}
-
-// ------------------------------------------------------------------------------------------ workspace
-struct DenWs {
-    size_t emb, h1, s, dvec, hvec, x, skip, y, h, g, sig, tnh, total;
-    size_t act_stride;  // per-layer stride of h/g/sig/tnh (0 when not saving)
-};
-
-static DenWs den_ws(const mg_denoiser_dims *d, int B, int L, int save)
-{
-    const size_t C = d->channels, NL = d->n_layers;
-    const size_t act = mg_align_up((size_t)B * C * L, 64);
-    DenWs w;
-    size_t p = 0;
-    auto take = [&](size_t n) {
-        size_t at = p;
-        p += mg_align_up(n, 64);
-        return at;
-    };
-    w.emb = take(B * C);
-    w.h1 = take(B * 4 * C);
-    w.s = take(B * C);
-    w.dvec = take(NL * B * C);
-    w.hvec = d->multi_speaker ? take(NL * B * C) : w.dvec;
-    w.x = take(act);
-    w.skip = take(act);
-    w.y = take(act);
-    w.act_stride = save ? act : 0;
-    const size_t nact = save ? NL : 1;
-    w.h = take(act * nact);
-    w.g = take(act * nact);
-    w.sig = save ? take(act * nact) : 0;
-    w.tnh = save ? take(act * nact) : 0;
-    w.total = p;
-    return w;
 }
 
 extern "C" size_t mg_denoiser_workspace_floats(const mg_denoiser_dims *d, int B, int L, int save_for_backward)
@@ -396,25 +256,25 @@ extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, c
     if (ws_floats < w.total) return MG_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int C = d->channels, H = d->cond_channels, M = d->mel_bins, NL = d->n_layers;
-    const DenLayout o = den_layout(d);
+    const DenLayout o = den_layout(d, 0);
     const float *lay0 = packed + o.layers;
 
     // step embedding -> MLP -> per-layer projections (model/modules.py:433-434, blocks.py:1159)
     hipLaunchKernelGGL(step_embed_kernel, dim3(mg_cdiv(B * (C / 2), 256)), dim3(256), 0, st, t, packed + o.freq,
                        ws + w.emb, B, C);
     MG_LAUNCH_CHECK();
-    MG_TRY(small_linear(packed + o.mlp0, 0, ws + w.emb, ws + w.h1, 0, nullptr, 0, B, 4 * C, C, 1, 1, st));
-    MG_TRY(small_linear(packed + o.mlp2, 0, ws + w.h1, ws + w.s, 0, nullptr, 0, B, C, 4 * C, 1, 0, st));
-    MG_TRY(small_linear(lay0 + o.l_wd, (long)o.layer_stride, ws + w.s, ws + w.dvec, (long)B * C, nullptr, 0, B, C, C, NL,
-                        0, st));
+    MG_TRY(small_linear(packed + o.mlp0, 0, ws + w.emb, ws + w.h1, 0, nullptr, 0, ws + w.h1pre, B, 4 * C, C, 1, 1, st));
+    MG_TRY(small_linear(packed + o.mlp2, 0, ws + w.h1, ws + w.s, 0, nullptr, 0, nullptr, B, C, 4 * C, 1, 0, st));
+    MG_TRY(small_linear(lay0 + o.l_wd, (long)o.layer_stride, ws + w.s, ws + w.dvec, (long)B * C, nullptr, 0, nullptr, B,
+                        C, C, NL, 0, st));
     if (d->multi_speaker)
         MG_TRY(small_linear(lay0 + o.l_wp, (long)o.layer_stride, spk, ws + w.hvec, (long)B * C, ws + w.dvec,
-                            (long)B * C, B, C, H, NL, 0, st));
+                            (long)B * C, nullptr, B, C, H, NL, 0, st));
 
     // input projection + ReLU (model/modules.py:430-431; the second relu is idempotent)
     {
         ConvShape s{B, M, L, L, 1, 1, 0, C, 0, 0};
-        EpiBiasAct::Params ep{ws + w.x, packed + o.in_b, nullptr, 1.f, C, MG_ACT_RELU, 0};
+        EpiBiasAct::Params ep{ws + w.x0, packed + o.in_b, nullptr, 1.f, C, MG_ACT_RELU, 0, 0, nullptr};
         MG_TRY(conv_launch<EpiBiasAct>(s, x_t, nullptr, packed + o.in_w, ep, st));
     }
     static const bool force_generic = std::getenv("MG_DENOISER_GENERIC") != nullptr;
@@ -422,7 +282,7 @@ extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, c
     if (fused) {
         // one launch per layer (resblock_fused.h); x ping-pongs between ws.x and ws.y
         const bool vec4 = (L % 4 == 0) && (((uintptr_t)cond & 15) == 0);
-        float *xa = ws + w.x, *xb = ws + w.y;
+        float *xa = ws + w.x0, *xb = ws + w.y, *xc = ws + w.x;  // x0 is preserved when saving
         for (int l = 0; l < NL; ++l) {
             const float *lp = lay0 + (size_t)l * o.layer_stride;
             ResArgs a;
@@ -456,11 +316,12 @@ extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, c
             }
             prof_mark(st, 1);
             MG_LAUNCH_CHECK();
-            float *tmp = xa;
+            float *tmp = (l == 0) ? xc : xa;  // after layer 0 the pair is (ws.y, ws.x)
             xa = xb;
             xb = tmp;
         }
-    } else
+    } else {
+    if (w.x0 != w.x) MG_TRY(copy_d2d(ws + w.x, ws + w.x0, (size_t)B * C * L, st));
     for (int l = 0; l < NL; ++l) {
         const float *lp = lay0 + (size_t)l * o.layer_stride;
         float *hbuf = ws + w.h + (size_t)l * w.act_stride;
@@ -484,15 +345,16 @@ extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, c
             MG_TRY(conv_launch<EpiResSkip>(s, gbuf, nullptr, lp + o.l_wo, ep, st));
         }
     }
+    }
     // sum(skips)/sqrt(NL) -> skip_projection -> ReLU -> output_projection (model/modules.py:441-444)
     {
         ConvShape s{B, C, L, L, 1, 1, 0, C, 0, 0};
-        EpiBiasAct::Params ep{ws + w.y, packed + o.skip_b, nullptr, 1.0f / sqrtf((float)NL), C, MG_ACT_RELU, 0};
+        EpiBiasAct::Params ep{ws + w.y, packed + o.skip_b, nullptr, 1.0f / sqrtf((float)NL), C, MG_ACT_RELU, 0, 0, nullptr};
         MG_TRY(conv_launch<EpiBiasAct>(s, ws + w.skip, nullptr, packed + o.skip_w, ep, st));
     }
     {
         ConvShape s{B, C, L, L, 1, 1, 0, M, 0, 0};
-        EpiBiasAct::Params ep{out, packed + o.out_b, nullptr, 1.f, M, MG_ACT_NONE, 0};
+        EpiBiasAct::Params ep{out, packed + o.out_b, nullptr, 1.f, M, MG_ACT_NONE, 0, 0, nullptr};
         MG_TRY(conv_launch<EpiBiasAct>(s, ws + w.y, nullptr, packed + o.out_w, ep, st));
     }
     return MG_OK;

@@ -1,0 +1,314 @@
+// Backward of Denoiser.forward (model/modules.py:420-446; what torch.autograd derives for the
+// reference) on gfx950.  Every contraction is an fp32-MFMA GEMM:
+//   data gradients  = the forward conv kernel on transposed, tap-flipped packs (MG_PACK_DGRAD);
+//   weight gradients = wgrad_mfma_kernel (frames are the reduction axis);
+// gate / ReLU / residual derivatives are fused into the data-gradient epilogues.  The 20
+// conditioner projections share their input, so their data gradient (K = 20*256) and their weight
+// gradient (M = 20*256) run as ONE GEMM each over the stacked per-layer dh.
+//
+// Per residual layer l (top to bottom), with dout = [dx_{l+1}/sqrt2 ; dS] kept in one [B,2C,L] buffer:
+//   dWo = dout (x) g_l                      dz  = gate'(Wo^T dout)        (EpiGateBwd)
+//   dW3 = dz (x) shift(h_l)                 dh  = W3^T (*) dz             (EpiDhBwd: dx_l = dh + dx_{l+1}/sqrt2)
+#include "denoiser_common.h"
+
+// ------------------------------------------------------------------------------------------ epilogues
+struct EpiGateBwd {
+    struct Params {
+        float *dz;         // [B, 2C, L]
+        const float *sig;  // [B, C, L] sigmoid(gate) saved by the forward
+        const float *tnh;  // [B, C, L] tanh(filter)
+        int C;
+    };
+    template <int WM>
+    static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][2], int b, int mrow0, int l0w,
+                                               int lane, int Lout)
+    {
+        const int h = lane >> 5, c = lane & 31;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = mrow0 + i * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                if (ch >= p.C) continue;
+                const size_t so = ((size_t)b * p.C + ch) * Lout;
+                const size_t zo = ((size_t)b * 2 * p.C + ch) * Lout;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int l = l0w + j * 32 + c;
+                    if (l < Lout) {
+                        const float dg = acc[i][j][r];
+                        const float s = p.sig[so + l], t = p.tnh[so + l];
+                        p.dz[zo + l] = dg * t * s * (1.f - s);                         // d/d gate pre-activation
+                        p.dz[zo + (size_t)p.C * Lout + l] = dg * s * (1.f - t * t);   // d/d filter pre-activation
+                    }
+                }
+            }
+        }
+    }
+};
+
+struct EpiDhBwd {
+    struct Params {
+        float *dh;       // this layer's [C, L] slice of dh_all [B, NL*C, L]
+        long dh_bs;      // NL*C*L
+        float *dout;     // [B, 2C, L]; rows < C hold dx_{l+1}/sqrt2 on entry, dx_l/sqrt2 on exit
+        int C;
+    };
+    template <int WM>
+    static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][2], int b, int mrow0, int l0w,
+                                               int lane, int Lout)
+    {
+        const int h = lane >> 5, c = lane & 31;
+        const float rs2 = 0.70710678118654752440f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = mrow0 + i * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                if (ch >= p.C) continue;
+                float *dh = p.dh + (size_t)b * p.dh_bs + (size_t)ch * Lout;
+                float *dx = p.dout + ((size_t)b * 2 * p.C + ch) * Lout;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int l = l0w + j * 32 + c;
+                    if (l < Lout) {
+                        const float v = acc[i][j][r];
+                        dh[l] = v;
+                        dx[l] = (v + dx[l]) * rs2;
+                    }
+                }
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------ tiny kernels
+// out[z][i][j] = sum_b a[z*a_zs + b*a_bs + i] * c[b*K + j]          (outer products over the batch)
+__global__ void small_outer_kernel(const float *__restrict__ a, long a_zs, long a_bs, const float *__restrict__ c,
+                                   float *__restrict__ out, int Z, int B, int N, int K)
+{
+    const size_t n = (size_t)Z * N * K;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % K);
+        const int i = (int)((idx / K) % N);
+        const int z = (int)(idx / ((size_t)K * N));
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s = fmaf(a[(size_t)z * a_zs + (size_t)b * a_bs + i], c[(size_t)b * K + j], s);
+        out[idx] = s;
+    }
+}
+
+// out[b][j] = sum_z sum_i W[z*w_zs + i*K + j] * a[z*a_zs + b*a_bs + i]   (transposed linears, summed over layers)
+__global__ void small_linear_t_kernel(const float *__restrict__ W, long w_zs, const float *__restrict__ a, long a_zs,
+                                      long a_bs, float *__restrict__ out, int Z, int B, int N, int K)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * K) return;
+    const int b = idx / K, j = idx - b * K;
+    float s = 0.f;
+    for (int z = 0; z < Z; ++z) {
+        const float *w = W + (size_t)z * w_zs + j;
+        const float *av = a + (size_t)z * a_zs + (size_t)b * a_bs;
+        for (int i = 0; i < N; ++i) s = fmaf(w[(size_t)i * K], av[i], s);
+    }
+    out[idx] = s;
+}
+
+// da = dm * mish'(x),  mish'(x) = tanh(sp) + x (1 - tanh(sp)^2) sigmoid(x),  sp = softplus(x)
+__global__ void mish_bwd_kernel(const float *__restrict__ dm, const float *__restrict__ x, float *__restrict__ da, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    const float ts = tanhf(mg_softplus(v));
+    const float sg = 1.f / (1.f + expf(-v));
+    da[i] = dm[i] * (ts + v * (1.f - ts * ts) * sg);
+}
+
+// out[b,c,l] = alpha * in[b*in_bs + c*L + l] * (mask[b,c,l] > 0)
+__global__ void scale_mask_kernel(const float *__restrict__ in, long in_bs, const float *__restrict__ mask,
+                                  float *__restrict__ out, float alpha, int CL, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / CL;
+        const size_t r = i - b * CL;
+        out[i] = mask[i] > 0.f ? alpha * in[b * in_bs + r] : 0.f;
+    }
+}
+
+// thin shim over the exported weight-gradient entry point (kernel lives in conv_api.hip)
+struct WgradShape {
+    int B, Co, Ci, Ldy, Lx, K, stride, pad;
+    long dy_bs, x_bs;
+};
+static int wgrad_launch(const WgradShape &s, const float *dy, const float *x, const float *xvec, float *dw,
+                        float *scratch, float alpha, int accumulate, hipStream_t st)
+{
+    return mg_conv1d_wgrad_strided(dy, s.dy_bs, x, s.x_bs, xvec, dw, scratch, s.B, s.Co, s.Ci, s.Ldy, s.Lx, s.K, s.stride,
+                                   s.pad, alpha, accumulate, st);
+}
+
+static int rowsum(const float *in, long in_bs, int B, int R, int L, float *out_r, float *out_br, float alpha,
+                  hipStream_t st)
+{
+    return mg_rowsum(in, in_bs, B, R, L, out_r, out_br, alpha, 0, st);
+}
+
+// ------------------------------------------------------------------------------------------ API
+extern "C" size_t mg_denoiser_bwd_workspace_floats(const mg_denoiser_dims *d, int B, int L)
+{
+    if (den_check(d) != MG_OK || B <= 0 || L <= 0) return 0;
+    return den_bws(d, B, L).total;
+}
+
+extern "C" int mg_denoiser_bwd(const mg_denoiser_dims *d, const float *packed, const float *g_out, const float *x_t,
+                               const float *cond, const float *spk, float *ws, float *bws, size_t bws_floats,
+                               float *const *grads, float *d_x_t, float *d_cond, float *d_spk, int B, int L,
+                               void *stream)
+{
+    MG_TRY(den_check(d));
+    if (!packed || !g_out || !x_t || !cond || !ws || !bws || !grads) return MG_ERR_ARG;
+    if (d->multi_speaker && !spk) return MG_ERR_ARG;
+    if (B <= 0 || L <= 0) return MG_ERR_SHAPE;
+    const int C = d->channels, H = d->cond_channels, M = d->mel_bins, NL = d->n_layers;
+    const DenLayout o = den_layout(d, 1);
+    const DenWs w = den_ws(d, B, L, 1);
+    const DenBws bw = den_bws(d, B, L);
+    if (bws_floats < bw.total) return MG_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float *const *lg0 = grads + MG_DEN_HEAD_PTRS;
+    auto LG = [&](int l, int j) { return lg0[(size_t)l * MG_DEN_LAYER_PTRS + j]; };
+    // batched outputs must be contiguous across layers
+    for (int l = 1; l < NL; ++l) {
+        if (LG(0, 2) && LG(l, 2) != LG(0, 2) + (size_t)l * C * C) return MG_ERR_ARG;
+        if (LG(0, 3) && LG(l, 3) != LG(0, 3) + (size_t)l * C * H) return MG_ERR_ARG;
+        if (LG(0, 4) && LG(l, 4) != LG(0, 4) + (size_t)l * C) return MG_ERR_ARG;
+        if (d->multi_speaker && LG(0, 7) && LG(l, 7) != LG(0, 7) + (size_t)l * C * H) return MG_ERR_ARG;
+    }
+    const size_t CL = (size_t)C * L;
+    float *dout = bws + bw.dout, *dz = bws + bw.dz, *dh_all = bws + bw.dh_all, *dy = bws + bw.dy;
+    float *dx0 = bws + bw.dx0, *scr = bws + bw.scratch;
+    const float rsNL = 1.0f / sqrtf((float)NL);
+
+    // ---- head: output_projection, ReLU, skip_projection (model/modules.py:441-444) ------------
+    {
+        ConvShape s{B, M, L, L, 1, 1, 0, C, 0, 0};
+        EpiBiasAct::Params ep{dy, nullptr, nullptr, 1.f, C, MG_ACT_NONE, 0, 0, ws + w.y};
+        MG_TRY(conv_launch<EpiBiasAct>(s, g_out, nullptr, packed + o.out_wT, ep, st));
+    }
+    if (grads[6]) {
+        WgradShape s{B, M, C, L, L, 1, 1, 0, 0, 0};
+        MG_TRY(wgrad_launch(s, g_out, ws + w.y, nullptr, grads[6], scr, 1.f, 0, st));
+    }
+    if (grads[7]) MG_TRY(rowsum(g_out, 0, B, M, L, grads[7], nullptr, 1.f, st));
+    {
+        ConvShape s{B, C, L, L, 1, 1, 0, C, 0, 0};
+        EpiBiasAct::Params ep{dout + CL, nullptr, nullptr, rsNL, C, MG_ACT_NONE, 0, (long)(2 * CL), nullptr};
+        MG_TRY(conv_launch<EpiBiasAct>(s, dy, nullptr, packed + o.skip_wT, ep, st));
+    }
+    if (grads[4]) {
+        WgradShape s{B, C, C, L, L, 1, 1, 0, 0, 0};
+        MG_TRY(wgrad_launch(s, dy, ws + w.skip, nullptr, grads[4], scr, rsNL, 0, st));
+    }
+    if (grads[5]) MG_TRY(rowsum(dy, 0, B, C, L, grads[5], nullptr, 1.f, st));
+    {   // the last layer's x output is unused: dx_NL = 0
+        hipError_t e = hipMemset2DAsync(dout, 2 * CL * sizeof(float), 0, CL * sizeof(float), B, st);
+        if (e != hipSuccess) return (int)e;
+    }
+
+    // ---- residual layers, top to bottom ------------------------------------------------------
+    for (int l = NL - 1; l >= 0; --l) {
+        const float *bp = packed + o.blayers + (size_t)l * o.blayer_stride;
+        const float *h_l = ws + w.h + (size_t)l * w.act_stride;
+        const float *g_l = ws + w.g + (size_t)l * w.act_stride;
+        const float *sig_l = ws + w.sig + (size_t)l * w.act_stride;
+        const float *tnh_l = ws + w.tnh + (size_t)l * w.act_stride;
+        if (LG(l, 5)) {
+            WgradShape s{B, 2 * C, C, L, L, 1, 1, 0, 0, 0};
+            MG_TRY(wgrad_launch(s, dout, g_l, nullptr, LG(l, 5), scr, 1.f, 0, st));
+        }
+        if (LG(l, 6)) MG_TRY(rowsum(dout, 0, B, 2 * C, L, LG(l, 6), nullptr, 1.f, st));
+        {
+            ConvShape s{B, 2 * C, L, L, 1, 1, 0, C, 0, 0};
+            EpiGateBwd::Params ep{dz, sig_l, tnh_l, C};
+            MG_TRY(conv_launch<EpiGateBwd>(s, dout, nullptr, bp + o.bl_woT, ep, st));
+        }
+        if (LG(l, 0)) {
+            WgradShape s{B, 2 * C, C, L, L, 3, 1, 1, 0, 0};
+            MG_TRY(wgrad_launch(s, dz, h_l, nullptr, LG(l, 0), scr, 1.f, 0, st));
+        }
+        if (LG(l, 1)) MG_TRY(rowsum(dz, 0, B, 2 * C, L, LG(l, 1), nullptr, 1.f, st));
+        {
+            ConvShape s{B, 2 * C, L, L, 3, 1, 1, C, 0, 0};
+            EpiDhBwd::Params ep{dh_all + (size_t)l * CL, (long)((size_t)NL * CL), dout, C};
+            MG_TRY(conv_launch<EpiDhBwd>(s, dz, nullptr, bp + o.bl_w3T, ep, st));
+        }
+        // d(Wd s)_l = sum_frames dx_l  (the step vector enters h and the residual, model/blocks.py:1166)
+        MG_TRY(rowsum(dout, (long)(2 * CL), B, C, L, nullptr, bws + bw.dd_all + (size_t)l * B * C, 1.41421356237309504880f,
+                      st));
+    }
+
+    // ---- input projection + ReLU (model/modules.py:430-431) -----------------------------------
+    {
+        const size_t n = (size_t)B * CL;
+        const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+        hipLaunchKernelGGL(scale_mask_kernel, dim3(blocks), dim3(256), 0, st, dout, (long)(2 * CL), ws + w.x0, dx0,
+                           1.41421356237309504880f, (int)CL, n);
+        MG_LAUNCH_CHECK();
+    }
+    if (grads[0]) {
+        WgradShape s{B, C, M, L, L, 1, 1, 0, 0, 0};
+        MG_TRY(wgrad_launch(s, dx0, x_t, nullptr, grads[0], scr, 1.f, 0, st));
+    }
+    if (grads[1]) MG_TRY(rowsum(dx0, 0, B, C, L, grads[1], nullptr, 1.f, st));
+    if (d_x_t) {
+        ConvShape s{B, C, L, L, 1, 1, 0, M, 0, 0};
+        EpiBiasAct::Params ep{d_x_t, nullptr, nullptr, 1.f, M, MG_ACT_NONE, 0, 0, nullptr};
+        MG_TRY(conv_launch<EpiBiasAct>(s, dx0, nullptr, packed + o.in_wT, ep, st));
+    }
+
+    // ---- conditioner projections, all layers at once -----------------------------------------
+    if (d_cond) {
+        ConvShape s{B, NL * C, L, L, 1, 1, 0, H, 0, 0};
+        EpiBiasAct::Params ep{d_cond, nullptr, nullptr, 1.f, H, MG_ACT_NONE, 0, 0, nullptr};
+        MG_TRY(conv_launch<EpiBiasAct>(s, dh_all, nullptr, packed + o.wc_allT, ep, st));
+    }
+    if (LG(0, 3)) {
+        WgradShape s{B, NL * C, H, L, L, 1, 1, 0, 0, 0};
+        MG_TRY(wgrad_launch(s, dh_all, cond, nullptr, LG(0, 3), scr, 1.f, 0, st));
+    }
+    if (LG(0, 4) || d->multi_speaker)
+        MG_TRY(rowsum(dh_all, 0, B, NL * C, L, LG(0, 4), d->multi_speaker ? bws + bw.dhv_all : nullptr, 1.f, st));
+
+    // ---- step-embedding MLP and per-layer step / speaker projections (tiny, per sample) --------
+    const float *lay0 = packed + o.layers;
+    auto outer = [&](const float *a, long a_zs, long a_bs, const float *c, float *out, int Z, int N, int K) {
+        const size_t n = (size_t)Z * N * K;
+        const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        hipLaunchKernelGGL(small_outer_kernel, dim3(blocks), dim3(256), 0, st, a, a_zs, a_bs, c, out, Z, B, N, K);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? MG_OK : (int)e;
+    };
+    auto linear_t = [&](const float *W, long w_zs, const float *a, long a_zs, long a_bs, float *out, int Z, int N,
+                        int K) {
+        hipLaunchKernelGGL(small_linear_t_kernel, dim3(mg_cdiv(B * K, 256)), dim3(256), 0, st, W, w_zs, a, a_zs, a_bs, out,
+                           Z, B, N, K);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? MG_OK : (int)e;
+    };
+    const float *dd_all = bws + bw.dd_all;
+    if (LG(0, 2)) MG_TRY(outer(dd_all, (long)B * C, C, ws + w.s, LG(0, 2), NL, C, C));
+    MG_TRY(linear_t(lay0 + o.l_wd, (long)o.layer_stride, dd_all, (long)B * C, C, bws + bw.ds, NL, C, C));
+    if (d->multi_speaker) {
+        const float *dhv = bws + bw.dhv_all;  // [B, NL*C]
+        if (LG(0, 7)) MG_TRY(outer(dhv, C, (long)NL * C, spk, LG(0, 7), NL, C, H));
+        if (d_spk) MG_TRY(linear_t(lay0 + o.l_wp, (long)o.layer_stride, dhv, C, (long)NL * C, d_spk, NL, C, H));
+    }
+    if (grads[3]) MG_TRY(outer(bws + bw.ds, 0, C, ws + w.h1, grads[3], 1, C, 4 * C));
+    MG_TRY(linear_t(packed + o.mlp2, 0, bws + bw.ds, 0, C, bws + bw.dm, 1, C, 4 * C));
+    hipLaunchKernelGGL(mish_bwd_kernel, dim3(mg_cdiv(B * 4 * C, 256)), dim3(256), 0, st, bws + bw.dm, ws + w.h1pre,
+                       bws + bw.da, B * 4 * C);
+    MG_LAUNCH_CHECK();
+    if (grads[2]) MG_TRY(outer(bws + bw.da, 0, 4 * C, ws + w.emb, grads[2], 1, 4 * C, C));
+    return MG_OK;
+}

@@ -1,0 +1,188 @@
+// Weight gradient of Conv1d / Linear on the fp32 MFMA (v_mfma_f32_32x32x2_f32), gfx950.
+//
+//   dW[co, ci, k] = alpha * sum_{b, l} dY[b, co, l] * (X[b, ci, l*stride + k - pad] + xvec[b, ci])
+//
+// Both operands are channel-major with the reduction axis (frames) contiguous, so the GEMM is
+// "NT": A[m = co][kk = frame], B[kk = frame][n = ci].  A workgroup owns a 128(co) x 128(ci) tile
+// of one tap and walks 64-frame chunks of the (batch, frame) axis; chunk tiles are staged in LDS
+// with an odd row stride (65) so that the 32 lanes of an MFMA fragment -- 32 different rows, same
+// column -- hit 32 different banks.  The frame axis is split across `nsplit` workgroups per tile
+// (the output is tiny compared with the reduction: 393k outputs vs 16k frames) and partial tiles
+// are combined with fp32 atomics into a tap-major scratch [K][Co][Ci] whose rows are contiguous in
+// ci (256-byte atomic wave-instructions, the full-rate shape of MI355X_MICROARCH.md "Global float
+// atomics"); a finalize kernel writes the [Co, Ci, K] parameter layout.
+#pragma once
+#include "common.h"
+
+#define WG_FT 64
+#define WG_RS 65
+#define WG_TILE (128 * WG_RS)
+
+struct WgradArgs {
+    const float *dy;    // [B, Co, Ldy] (batch stride dy_bs, row stride Ldy)
+    const float *x;     // [B, Ci, Lx]  (batch stride x_bs,  row stride Lx)
+    const float *xvec;  // optional [B, Ci]
+    float *scratch;     // [K][Co][Ci]
+    long dy_bs, x_bs;
+    int B, Co, Ci, Ldy, Lx, K, stride, pad;
+    int chunks_per_b, nchunks, nsplit, ci_tiles;
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a)
+{
+    __shared__ float lds[2][WG_TILE];  // [A|B], single-buffered (66.5 KB -> two workgroups per CU)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int hh = lane >> 5, c32 = lane & 31;
+    const int split = blockIdx.x;
+    const int co0 = (blockIdx.y / a.ci_tiles) * 128;
+    const int ci0 = (blockIdx.y % a.ci_tiles) * 128;
+    const int tap = blockIdx.z;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float sa[32], sb[32];
+    auto load_stage = [&](int chunk) {
+        const int b = chunk / a.chunks_per_b;
+        const int f0 = (chunk - b * a.chunks_per_b) * WG_FT;
+        const float *dyb = a.dy + (size_t)b * a.dy_bs;
+        const float *xb = a.x + (size_t)b * a.x_bs;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const int idx = tid + k * 256;  // 128 rows x 64 frames
+            const int row = idx >> 6, c = idx & 63;
+            const int f = f0 + c;
+            {
+                const int co = co0 + row;
+                const bool ok = co < a.Co && f < a.Ldy;
+                const float v = dyb[(size_t)min(co, a.Co - 1) * a.Ldy + min(f, a.Ldy - 1)];
+                sa[k] = ok ? v : 0.f;
+            }
+            {
+                const int ci = ci0 + row;
+                const int xf = f * a.stride + tap - a.pad;
+                const bool ok = ci < a.Ci && f < a.Ldy && xf >= 0 && xf < a.Lx;
+                const int cic = min(ci, a.Ci - 1);
+                float v = xb[(size_t)cic * a.Lx + min(max(xf, 0), a.Lx - 1)];
+                if (a.xvec) v += a.xvec[(size_t)b * a.Ci + cic];
+                sb[k] = ok ? v : 0.f;
+            }
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const int idx = tid + k * 256;
+            const int row = idx >> 6, c = idx & 63;
+            lds[0][row * WG_RS + c] = sa[k];
+            lds[1][row * WG_RS + c] = sb[k];
+        }
+    };
+
+    int chunk = split;
+    if (chunk < a.nchunks) {
+        load_stage(chunk);
+        store_stage();
+    }
+    __syncthreads();
+    const float *A = lds[0] + (wm * 64 + c32) * WG_RS + hh;
+    const float *Bt = lds[1] + (wn * 64 + c32) * WG_RS + hh;
+    for (; chunk < a.nchunks; chunk += a.nsplit) {
+        const bool more = chunk + a.nsplit < a.nchunks;
+        if (more) load_stage(chunk + a.nsplit);  // global loads fly behind the MFMAs below
+#pragma unroll 8
+        for (int s = 0; s < WG_FT / 2; ++s) {
+            const float a0 = A[2 * s], a1 = A[32 * WG_RS + 2 * s];
+            const float b0 = Bt[2 * s], b1 = Bt[32 * WG_RS + 2 * s];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();  // every wave is done reading the tiles
+        if (more) store_stage();
+        __syncthreads();
+    }
+
+    // acc[i][j][r]: co = co0 + wm*64 + i*32 + 8*(r>>2) + 4*hh + (r&3),  ci = ci0 + wn*64 + j*32 + c32
+    float *dst = a.scratch + (size_t)tap * a.Co * a.Ci;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
+            if (co >= a.Co) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ci = ci0 + wn * 64 + j * 32 + c32;
+                if (ci < a.Ci) atomicAdd(dst + (size_t)co * a.Ci + ci, acc[i][j][r]);
+            }
+        }
+}
+
+// scratch [K][Co][Ci] -> dw [Co][Ci][K] (= or +=), scaled
+__global__ void wgrad_finalize_kernel(const float *__restrict__ scratch, float *__restrict__ dw, int Co, int Ci, int K,
+                                      float alpha, int accumulate)
+{
+    const size_t n = (size_t)Co * Ci * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const size_t cc = i / K;  // co*Ci + ci
+        const float v = alpha * scratch[(size_t)k * Co * Ci + cc];
+        dw[i] = accumulate ? dw[i] + v : v;
+    }
+}
+
+struct WgradShape {
+    int B, Co, Ci, Ldy, Lx, K, stride, pad;
+    long dy_bs, x_bs;  // 0 -> dense
+};
+
+static int wgrad_launch(const WgradShape &s, const float *dy, const float *x, const float *xvec, float *dw,
+                        float *scratch, float alpha, int accumulate, hipStream_t st)
+{
+    if (s.B <= 0 || s.Co <= 0 || s.Ci <= 0 || s.Ldy <= 0 || s.Lx <= 0 || s.K <= 0) return MG_ERR_SHAPE;
+    WgradArgs a;
+    a.dy = dy;
+    a.x = x;
+    a.xvec = xvec;
+    a.scratch = scratch;
+    a.dy_bs = s.dy_bs ? s.dy_bs : (long)s.Co * s.Ldy;
+    a.x_bs = s.x_bs ? s.x_bs : (long)s.Ci * s.Lx;
+    a.B = s.B;
+    a.Co = s.Co;
+    a.Ci = s.Ci;
+    a.Ldy = s.Ldy;
+    a.Lx = s.Lx;
+    a.K = s.K;
+    a.stride = s.stride;
+    a.pad = s.pad;
+    a.chunks_per_b = mg_cdiv(s.Ldy, WG_FT);
+    a.nchunks = a.chunks_per_b * s.B;
+    a.ci_tiles = mg_cdiv(s.Ci, 128);
+    const int tiles = mg_cdiv(s.Co, 128) * a.ci_tiles * s.K;
+    int nsplit = mg_cdiv(512, tiles);  // two workgroups per CU in flight
+    if (nsplit > a.nchunks) nsplit = a.nchunks;
+    if (nsplit < 1) nsplit = 1;
+    a.nsplit = nsplit;
+    const size_t n = (size_t)s.Co * s.Ci * s.K;
+    hipError_t e = hipMemsetAsync(scratch, 0, n * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid(nsplit, mg_cdiv(s.Co, 128) * a.ci_tiles, s.K);
+    hipLaunchKernelGGL(wgrad_mfma_kernel, grid, dim3(256), 0, st, a);
+    MG_LAUNCH_CHECK();
+    const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, st, scratch, dw, s.Co, s.Ci, s.K, alpha,
+                       accumulate);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
+}

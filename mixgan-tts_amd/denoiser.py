@@ -41,6 +41,8 @@ class Denoiser(nn.Module):
         self._packed = None
         self._packed_key = None
         self._ws = {}
+        self._bws = {}
+        self._save_gen = 0
 
     # ------------------------------------------------------------------ packed-weight cache
     def _weight_table(self):
@@ -56,22 +58,24 @@ class Denoiser(nn.Module):
                   blk.speaker_projection.linear.weight if self.multi_speaker else None, None]
         return t
 
-    def packed_weights(self):
+    def packed_weights(self, with_backward=False):
         """The MFMA-ordered weight blob: a derived cache, rebuilt when any parameter changes
-        (optimizer step, load_state_dict, .to())."""
+        (optimizer step, load_state_dict, .to()).  with_backward adds the transposed packs."""
         table = self._weight_table()
-        key = tuple((p.data_ptr(), p._version) for p in table if p is not None)
+        with_backward = bool(with_backward) or (self._packed_key is not None and self._packed_key[0])
+        key = (with_backward,) + tuple((p.data_ptr(), p._version) for p in table if p is not None)
         if self._packed is None or key != self._packed_key:
             L = _lib.lib()
             dev = table[0].device
             if dev.type != "cuda":
                 raise _lib.MixganHipError("Denoiser parameters are on %s: the HIP path needs them on the GPU" % dev)
-            n = L.mg_denoiser_packed_floats(ctypes.byref(self._dims))
+            n = L.mg_denoiser_packed_floats(ctypes.byref(self._dims), int(with_backward))
             if self._packed is None or self._packed.numel() != n or self._packed.device != dev:
                 self._packed = torch.empty(n, device=dev, dtype=torch.float32)
             ptrs = (ctypes.c_void_p * len(table))(*[None if p is None else fptr(p.detach()).value for p in table])
             freq = self.diffusion_embedding.frequencies(dev).contiguous()
-            check(L.mg_denoiser_pack(ctypes.byref(self._dims), ptrs, fptr(freq), fptr(self._packed), stream_ptr()))
+            check(L.mg_denoiser_pack(ctypes.byref(self._dims), ptrs, fptr(freq), fptr(self._packed),
+                                     int(with_backward), stream_ptr()))
             self._packed_key = key
         return self._packed
 
@@ -91,8 +95,10 @@ class Denoiser(nn.Module):
         """x_t [B,M,L], t int64 [B], cond [B,H,L] contiguous, spk [B,H]|None -> [B,M,L] (no autograd)."""
         B, M, L = x_t.shape
         if packed is None:
-            packed = self.packed_weights()
+            packed = self.packed_weights(with_backward=save)
         ws = self._workspace(B, L, save, x_t.device)
+        if save:
+            self._save_gen += 1
         if out is None:
             out = torch.empty_like(x_t)
         check(_lib.lib().mg_denoiser_fwd(ctypes.byref(self._dims), fptr(packed), fptr(x_t), iptr(t, torch.int64),
@@ -115,3 +121,44 @@ class Denoiser(nn.Module):
             from .autograd import DenoiserFn
             return DenoiserFn.apply(self, x, t, cond, spk, *[p for p in self._weight_table() if p is not None])[:, None]
         return self.run(x, t, cond, spk)[:, None]
+
+    # ------------------------------------------------------------------ backward (autograd.DenoiserFn)
+    def run_backward(self, g_out, x_t, t, cond, spk, gen, want_dx, want_dcond, want_dspk):
+        """Returns (d_x_t, d_cond, d_spk, [param grads in weight-table order, None entries skipped])."""
+        if gen != self._save_gen:
+            raise _lib.MixganHipError(
+                "Denoiser backward: the saved activations were overwritten by a later forward of the same "
+                "module (call backward before the next grad-enabled forward, as train.py does)")
+        L_ = _lib.lib()
+        B, M, L = x_t.shape
+        dev = x_t.device
+        d = self._dims
+        NL, C, H = d.n_layers, d.channels, d.cond_channels
+        packed = self.packed_weights(with_backward=True)
+        ws = self._workspace(B, L, True, dev)
+        k = (B, L, dev)
+        bws = self._bws.get(k)
+        if bws is None:
+            if len(self._bws) > 4:
+                self._bws.clear()
+            bws = torch.empty(L_.mg_denoiser_bwd_workspace_floats(ctypes.byref(d), B, L), device=dev)
+            self._bws[k] = bws
+        table = self._weight_table()
+        new = lambda p: torch.empty_like(p)
+        grads = [new(p) if p is not None else None for p in table[:8]]
+        g_wd = torch.empty(NL, C, C, device=dev)
+        g_wc = torch.empty(NL, C, H, 1, device=dev)
+        g_bc = torch.empty(NL, C, device=dev)
+        g_wp = torch.empty(NL, C, H, device=dev) if self.multi_speaker else None
+        for l, blk in enumerate(self.residual_layers):
+            grads += [new(blk.conv_layer.conv.weight), new(blk.conv_layer.conv.bias), g_wd[l], g_wc[l], g_bc[l],
+                      new(blk.output_projection.conv.weight), new(blk.output_projection.conv.bias),
+                      g_wp[l] if self.multi_speaker else None, None]
+        ptrs = (ctypes.c_void_p * len(grads))(*[None if g is None else g.data_ptr() for g in grads])
+        d_x = torch.empty_like(x_t) if want_dx else None
+        d_cond = torch.empty_like(cond) if want_dcond else None
+        d_spk = torch.empty_like(spk) if (want_dspk and spk is not None) else None
+        check(L_.mg_denoiser_bwd(ctypes.byref(d), fptr(packed), fptr(g_out), fptr(x_t), fptr(cond),
+                                 fptr(spk, not self.multi_speaker), fptr(ws), fptr(bws), bws.numel(), ptrs,
+                                 fptr(d_x, True), fptr(d_cond, True), fptr(d_spk, True), B, L, stream_ptr()))
+        return d_x, d_cond, d_spk, [g for g in grads if g is not None]

@@ -110,3 +110,25 @@ def spec_affine(x, spec_min, spec_max, mode):
     check(L.mg_spec_affine(fptr(x), fptr(out), fptr(spec_min.reshape(-1)), fptr(spec_max.reshape(-1)), mode,
                            x.numel(), M, stream_ptr()))
     return out
+
+
+def conv1d_wgrad(dy, x, K, stride=1, padding=0, x_vec=None, alpha=1.0):
+    """dW [Co, Ci, K] of conv1d(x, W): dy [B,Co,Ldy], x [B,Ci,Lx]."""
+    L = _lib.lib()
+    B, Co, Ldy = dy.shape
+    _, Ci, Lx = x.shape
+    dw = torch.empty(Co, Ci, K, device=x.device, dtype=torch.float32)
+    scratch = torch.empty(L.mg_conv1d_wgrad_scratch_floats(Co, Ci, K), device=x.device, dtype=torch.float32)
+    check(L.mg_conv1d_wgrad(fptr(dy), fptr(x), fptr(x_vec, True), fptr(dw), fptr(scratch), B, Co, Ci, Ldy, Lx, K,
+                            stride, padding, float(alpha), 0, stream_ptr()))
+    return dw
+
+
+def rowsum(x, per_batch=False, alpha=1.0):
+    """x [B,R,L] -> [R] (sum over b,l) or [B,R] (sum over l)."""
+    L = _lib.lib()
+    B, R, Lf = x.shape
+    out = torch.empty((B, R) if per_batch else (R,), device=x.device, dtype=torch.float32)
+    check(L.mg_rowsum(fptr(x), 0, B, R, Lf, fptr(None if per_batch else out, True), fptr(out if per_batch else None, True),
+                      float(alpha), 0, stream_ptr()))
+    return out

@@ -1,0 +1,127 @@
+"""GPU parity of the backward path (mg_conv1d_wgrad, mg_rowsum, mg_denoiser_bwd, the autograd
+wrappers) against the reference fixtures (gradients recorded from the real reference) and against
+torch.autograd on the CPU oracle.  Tolerance 5e-5 (max-abs err / max-abs ref): fp32 sums over up to
+B*L frames in a different order (split-K + atomics for weight gradients)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import (golden, T, seeded, assert_close, assert_digest, hot_path_configs, write_stats, load_seeded, Tape)
+from oracle import refmath as R
+
+pytestmark = pytest.mark.gpu
+GT = 5e-5
+
+
+@pytest.fixture(scope="module")
+def mg():
+    import mixgan_tts_amd as m
+    assert torch.cuda.is_available()
+    m.lib()
+    return m
+
+
+def dev(a):
+    return (T(a) if isinstance(a, np.ndarray) else a).cuda()
+
+
+@pytest.mark.parametrize("Ci,Co,K,stride,L", [
+    (256, 512, 3, 1, 130), (256, 512, 1, 1, 64), (80, 256, 1, 1, 37), (256, 80, 1, 1, 200),
+    (64, 128, 5, 2, 37), (128, 512, 5, 2, 300), (128, 1, 3, 1, 10), (7, 5, 3, 1, 3), (160, 64, 3, 1, 1000),
+])
+def test_wgrad_matches_autograd(mg, Ci, Co, K, stride, L):
+    g = torch.Generator().manual_seed(Ci + Co * 7 + K)
+    B = 3
+    pad = (K - 1) // 2
+    x = torch.randn(B, Ci, L, generator=g)
+    w = (torch.randn(Co, Ci, K, generator=g) / (Ci * K) ** 0.5).requires_grad_()
+    y = F.conv1d(x, w, None, stride=stride, padding=pad)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    dw = mg.ops.conv1d_wgrad(gy.cuda(), x.cuda(), K, stride, pad)
+    assert_close(dw.cpu(), w.grad, 2e-5, "wgrad")
+    assert_close(mg.ops.rowsum(gy.cuda()).cpu(), gy.sum((0, 2)), 2e-5, "bias grad")
+    assert_close(mg.ops.rowsum(gy.cuda(), per_batch=True).cpu(), gy.sum(2), 2e-5, "per-sample sums")
+
+
+def test_wgrad_xvec(mg):
+    g = torch.Generator().manual_seed(4)
+    B, Ci, Co, L, K = 2, 512, 128, 70, 5
+    x, v = torch.randn(B, Ci, L, generator=g), torch.randn(B, Ci, generator=g)
+    w = (torch.randn(Co, Ci, K, generator=g) / 50).requires_grad_()
+    gy = torch.randn(B, Co, L, generator=g)
+    F.conv1d(x + v[:, :, None], w, None, padding=2).backward(gy)
+    dw = mg.ops.conv1d_wgrad(gy.cuda(), x.cuda(), K, 1, 2, x_vec=v.cuda())
+    assert_close(dw.cpu(), w.grad, 2e-5, "wgrad with input vector")
+
+
+@pytest.mark.parametrize("ms", [0, 1])
+def test_denoiser_backward_golden(mg, manifest, tmp_path, ms):
+    name = "denoiser_ms%d" % ms
+    g = golden(name)
+    _, pre, mc, _ = hot_path_configs(multi_speaker=bool(ms), stats_dir=str(tmp_path))
+    den = mg.Denoiser(pre, mc)
+    load_seeded(den, manifest, name, 21 + ms)
+    den = den.cuda()
+    x, cond = dev(g["x"]).requires_grad_(), dev(g["cond"]).requires_grad_()
+    spk = dev(g["spk"]).requires_grad_() if ms else None
+    out = den(x, dev(g["t"]), cond, spk)
+    assert_close(out.detach().cpu(), g["out"], 2e-5, "forward (save path)")
+    (out * dev(g["go"])).sum().backward()
+    torch.cuda.synchronize()
+    assert_close(x.grad.cpu(), g["d_x"], GT, "d_x")
+    assert_close(cond.grad.cpu(), g["d_cond"], GT, "d_cond")
+    if ms:
+        assert_close(spk.grad.cpu(), g["d_spk"], GT, "d_spk")
+    for k, p in den.named_parameters():
+        assert p.grad is not None, k
+        assert_digest(p.grad, g, k, 1e-4)
+
+
+@pytest.mark.parametrize("model,ms", [("naive", 0), ("naive", 1), ("shallow", 0)])
+def test_gaussian_diffusion_training_gradients(mg, manifest, tmp_path, model, ms):
+    name = "diffusion_%s_ms%d" % (model, ms)
+    g = golden(name)
+    e = golden("elementwise")
+    stats = write_stats(tmp_path, e["spec_min"], e["spec_max"])
+    gd = mg.GaussianDiffusion(*hot_path_configs(model, 4, multi_speaker=bool(ms), stats_dir=stats))
+    load_seeded(gd, manifest, name, 31 + ms)
+    gd = gd.cuda().train()
+    mel, pad = dev(g["mel"]), dev(g["pad"])
+    cond = dev(g["cond"]).requires_grad_()
+    spk = dev(g["spk"]) if ms else None
+    coarse = dev(g["coarse"]) if model == "shallow" else None
+    gd.t_fn = Tape([g["t"]])
+    gd.noise_fn = Tape([g["n_xt"], g["n_prev"], g["n_post"]])
+    x0p, x_t, x_prev, x_pp, t = gd(mel, cond, spk, pad, coarse)
+    assert_close(x0p.detach().cpu(), g["x0_pred"], 2e-5, "x0_pred")
+    assert_close(x_pp.detach().cpu(), g["x_prev_pred"], 2e-5, "x_prev_pred")
+    ((x0p * dev(g["w1"])).sum() + (x_pp * dev(g["w2"])).sum()).backward()
+    assert_close(cond.grad.cpu(), g["d_cond"], GT, "d_cond")
+    params = dict(gd.named_parameters())
+    for k in [k[len("dw_sum/"):] for k in g if k.startswith("dw_sum/")]:
+        assert_digest(params[k].grad, g, k, 1e-4)
+
+
+def test_denoiser_backward_vs_oracle_autograd_ragged(mg, manifest, tmp_path):
+    """B, L not covered by fixtures (tile boundaries, L % 4 != 0): compare with torch.autograd on the oracle."""
+    _, pre, mc, _ = hot_path_configs(stats_dir=str(tmp_path))
+    den = mg.Denoiser(pre, mc)
+    load_seeded(den, manifest, "denoiser_ms0", 78)
+    den = den.cuda()
+    W, _ = seeded(manifest, "denoiser_ms0", 78, requires_grad=True)
+    gen = torch.Generator().manual_seed(2)
+    B, L = 3, 131
+    x = torch.randn(B, 1, 80, L, generator=gen)
+    cond = torch.randn(B, 256, L, generator=gen)
+    t = torch.tensor([0, 999, 17])
+    go = torch.randn(B, 1, 80, L, generator=gen)
+    xr, cr = x.clone().requires_grad_(), cond.clone().requires_grad_()
+    (R.denoiser_forward(W, "", xr, t, cr, None) * go).sum().backward()
+    xg, cg = x.cuda().requires_grad_(), cond.cuda().requires_grad_()
+    (den(xg, t.cuda(), cg, None) * go.cuda()).sum().backward()
+    assert_close(xg.grad.cpu(), xr.grad, GT, "d_x")
+    assert_close(cg.grad.cpu(), cr.grad, GT, "d_cond")
+    for k, p in den.named_parameters():
+        assert_close(p.grad.cpu(), W[k].grad, 1e-4, k)
