@@ -128,6 +128,11 @@ int mg_spec_affine(const float *in, float *out, const float *spec_min, const flo
  * mode 0 plain, 1 norm_spec on the way in (BLM->BML), 2 denorm_spec on the way out (BML->BLM). */
 int mg_transpose_bml(const float *in, float *out, const float *spec_min, const float *spec_max,
                      const uint8_t *keep, int to_blm, int mode, int B, int L, int M, void *stream);
+/* Same, with the [B,M,L] side being an M-channel slice of a wider tensor (batch stride bml_bs floats):
+ * builds torch.cat([x_t_prevs, x_ts], -1).transpose(1,2) (model/mixgantts.py:262-264) without a copy. */
+int mg_transpose_bml_strided(const float *in, float *out, const float *spec_min, const float *spec_max,
+                             const uint8_t *keep, int to_blm, int mode, int B, int L, int M, long bml_bs,
+                             void *stream);
 
 /* ------------------------------------------------------------------ Denoiser (model/modules.py:382-446)
  * Weight pointer table order for mg_denoiser_pack (names are the reference state_dict keys under
@@ -184,6 +189,26 @@ int mg_denoiser_bwd(const mg_denoiser_dims *d, const float *packed, const float 
                     const float *x_t, const float *cond, const float *spk, float *workspace,
                     float *bwd_workspace, size_t bwd_workspace_floats, float *const *grads,
                     float *d_x_t, float *d_cond, float *d_spk, int B, int L, void *stream);
+
+/* ------------------------------------------------------------------ pieces of autograd around the GEMMs
+ * dpre = dy * act'(.) written through the saved OUTPUT y = act(pre) (ReLU / LeakyReLU(0.2) / tanh). */
+int mg_act_bwd(const float *dy, const float *y, float *out, int act, size_t n, void *stream);
+/* Zero insertion out[r, j] = in[r, j/stride] if stride | j else 0 (j < Lup): turns the data gradient
+ * of a strided Conv1d (model/mixgantts.py:219-228, strides [1,2,2]) into a stride-1 convolution. */
+int mg_upsample_zero(const float *in, float *out, int rows, int Lin, int stride, int Lup, void *stream);
+
+/* Step-embedding MLP: out = W2 mish(W0 [sin|cos](t * freq)).  Denoiser: model/modules.py:398-403,434;
+ * JCUDiscriminator: model/mixgantts.py:203-208,265.  emb [B,D0], pre/h [B,D1] are saved for backward. */
+int mg_step_mlp_fwd(const int64_t *t, const float *freq, const float *W0, const float *W2, float *emb,
+                    float *pre, float *h, float *out, int B, int D0, int D1, int D2, void *stream);
+/* g_out [B,D2] -> dW0 [D1,D0], dW2 [D2,D1]; scratch 2*B*D1 floats. */
+int mg_step_mlp_bwd(const float *g_out, const float *emb, const float *pre, const float *h,
+                    const float *W2, float *dW0, float *dW2, float *scratch, int B, int D0, int D1, int D2,
+                    void *stream);
+/* Bias-free per-sample Linear (LinearNorm on [B,K] vectors: speaker projections, spk_mlp). */
+int mg_linear_small_fwd(const float *x, const float *W, float *out, int B, int N, int K, void *stream);
+int mg_linear_small_bwd(const float *g, const float *x, const float *W, float *dx, float *dW, int B,
+                        int N, int K, void *stream);
 
 /* ------------------------------------------------------------------ measurement hooks (bench.py)
  * While a session is open, mg_denoiser_fwd brackets each launch of its dominant kernel (the k=3

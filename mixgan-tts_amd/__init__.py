@@ -12,5 +12,7 @@ from .schedule import beta_schedule, diffusion_buffers  # noqa: F401
 from .blocks import ConvNorm, LinearNorm, DiffusionEmbedding, Mish, ResidualBlock  # noqa: F401
 from .denoiser import Denoiser  # noqa: F401
 from .diffusion import GaussianDiffusion  # noqa: F401
+from .discriminator import JCUDiscriminator  # noqa: F401
+from . import ops, autograd  # noqa: F401
 
 __version__ = "0.1.0"

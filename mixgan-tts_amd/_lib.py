@@ -15,7 +15,8 @@ EXPORTS = (
     "mg_diffuse_fwd", "mg_posterior_sample_fwd", "mg_posterior_sample_bwd", "mg_spec_affine", "mg_transpose_bml",
     "mg_denoiser_packed_floats", "mg_denoiser_pack", "mg_denoiser_workspace_floats", "mg_denoiser_fwd",
     "mg_denoiser_bwd_workspace_floats", "mg_denoiser_bwd",
-    "mg_profile_begin", "mg_profile_end",
+    "mg_profile_begin", "mg_profile_end", "mg_transpose_bml_strided", "mg_act_bwd", "mg_upsample_zero",
+    "mg_step_mlp_fwd", "mg_step_mlp_bwd", "mg_linear_small_fwd", "mg_linear_small_bwd",
 )
 
 
@@ -81,6 +82,13 @@ def _declare(L):
         "mg_denoiser_bwd": (i, [dp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, i, i, vp]),
         "mg_denoiser_workspace_floats": (sz, [dp, i, i, i]),
         "mg_denoiser_fwd": (i, [dp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, vp]),
+        "mg_transpose_bml_strided": (i, [vp] * 5 + [i, i, i, i, i, ctypes.c_long, vp]),
+        "mg_act_bwd": (i, [vp, vp, vp, i, sz, vp]),
+        "mg_upsample_zero": (i, [vp, vp, i, i, i, i, vp]),
+        "mg_step_mlp_fwd": (i, [vp] * 8 + [i, i, i, i, vp]),
+        "mg_step_mlp_bwd": (i, [vp] * 8 + [i, i, i, i, vp]),
+        "mg_linear_small_fwd": (i, [vp, vp, vp, i, i, i, vp]),
+        "mg_linear_small_bwd": (i, [vp, vp, vp, vp, vp, i, i, i, vp]),
         "mg_profile_begin": (i, [i]),
         "mg_profile_end": (i, [vp, i]),
     }

@@ -111,3 +111,103 @@ class _PosteriorFn(torch.autograd.Function):
         g = ops.posterior_sample_bwd(x0, t, keep, c1, g_x0c.contiguous(),
                                      g_xpp.contiguous() if ctx.through else None, ctx.clip)
         return (g,) + (None,) * 9
+
+
+# --------------------------------------------------------------------------------------------------
+# differentiable building blocks for the JCU discriminator and the FFT blocks: every forward and
+# backward below is a call into the HIP library; torch.autograd only chains them.
+# --------------------------------------------------------------------------------------------------
+class _Conv1dFn(torch.autograd.Function):
+    """y = act(conv1d(x (+ in_vec), W, b)); x [B,Ci,L] channel-major."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, in_vec, stride, padding, act):
+        _require_cuda(x)
+        x = x.contiguous()
+        Co, Ci, K = weight.shape
+        y = ops.conv1d_packed(x, ops.pack_cached(weight), None if bias is None else bias.detach(), Co, K, stride,
+                              padding, act, in_vec=None if in_vec is None else in_vec.detach().contiguous())
+        ctx.save_for_backward(x, weight, y if act else None, in_vec)
+        ctx.cfg = (stride, padding, act, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y, in_vec = ctx.saved_tensors
+        stride, padding, act, has_bias = ctx.cfg
+        Co, Ci, K = weight.shape
+        gy = gy.contiguous()
+        dpre = ops.act_bwd(gy, y, act) if act else gy
+        need = ctx.needs_input_grad
+        vec = None if in_vec is None else in_vec.detach().contiguous()
+        dw = ops.conv1d_wgrad(dpre, x, K, stride, padding, x_vec=vec) if need[1] else None
+        db = ops.rowsum(dpre) if (has_bias and need[2]) else None
+        dx = dvec = None
+        if need[0] or (in_vec is not None and need[3]):
+            Lin = x.shape[2]
+            src = dpre
+            if stride > 1:
+                src = ops.upsample_zero(dpre, stride, (dpre.shape[2] - 1) * stride + 1)
+            dx = ops.conv1d_packed(src, ops.pack_cached(weight, ops.PACK_DGRAD), None, Ci, K, 1, K - 1 - padding,
+                                   Lout=Lin)
+            if in_vec is not None and need[3]:
+                dvec = ops.rowsum(dx, per_batch=True)
+        return dx if need[0] else None, dw, db, dvec, None, None, None
+
+
+def conv1d(x, weight, bias=None, stride=1, padding=0, act=None, in_vec=None):
+    return _Conv1dFn.apply(x, weight, bias, in_vec, stride, padding, act)
+
+
+class _StepMlpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, freq, W0, W2):
+        out, emb, pre, h = ops.step_mlp_fwd(t.contiguous(), freq, W0.detach().contiguous(), W2.detach().contiguous())
+        ctx.save_for_backward(emb, pre, h, W2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        emb, pre, h, W2 = ctx.saved_tensors
+        dW0, dW2 = ops.step_mlp_bwd(g.contiguous(), emb, pre, h, W2.detach().contiguous())
+        return None, None, dW0, dW2
+
+
+def step_mlp(t, freq, W0, W2):
+    _require_cuda(W0)
+    return _StepMlpFn.apply(t, freq, W0, W2)
+
+
+class _LinearSmallFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W):
+        ctx.save_for_backward(x, W)
+        return ops.linear_small_fwd(x.contiguous(), W.detach().contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        dx, dW = ops.linear_small_bwd(g.contiguous(), x.contiguous(), W.detach().contiguous(), ctx.needs_input_grad[0])
+        return dx, dW
+
+
+def linear_small(x, W):
+    _require_cuda(x)
+    return _LinearSmallFn.apply(x, W)
+
+
+class _CatTransposeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.M = a.shape[-1]
+        return ops.cat_transpose(a.contiguous(), b.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        da, db = ops.split_transpose(g.contiguous(), ctx.M)
+        return da, db
+
+
+def cat_transpose(a, b):
+    _require_cuda(a, b)
+    return _CatTransposeFn.apply(a, b)

@@ -103,7 +103,6 @@ extern "C" int mg_conv1d_fwd(const float *in, const float *in_vec, const float *
     if (!in || !packed || !out) return MG_ERR_ARG;
     if (act < 0 || act > MG_ACT_TANH) return MG_ERR_ARG;
     if (B <= 0 || Ci <= 0 || Co <= 0 || Lin <= 0 || Lout <= 0 || pad < 0) return MG_ERR_SHAPE;
-    if ((Lin + 2 * pad - K) / stride + 1 < Lout) return MG_ERR_SHAPE;  // would read past the padded input
     ConvShape s{B, Ci, Lin, Lout, K, stride, pad, Co, 0, 0};
     EpiBiasAct::Params ep{out, bias, add, alpha, Co, act, accumulate, 0, nullptr};
     return conv_launch<EpiBiasAct>(s, in, in_vec, packed, ep, (hipStream_t)stream);

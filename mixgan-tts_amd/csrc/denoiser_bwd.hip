@@ -82,60 +82,6 @@ struct EpiDhBwd {
     }
 };
 
-// ------------------------------------------------------------------------------------------ tiny kernels
-// out[z][i][j] = sum_b a[z*a_zs + b*a_bs + i] * c[b*K + j]          (outer products over the batch)
-__global__ void small_outer_kernel(const float *__restrict__ a, long a_zs, long a_bs, const float *__restrict__ c,
-                                   float *__restrict__ out, int Z, int B, int N, int K)
-{
-    const size_t n = (size_t)Z * N * K;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
-        const int j = (int)(idx % K);
-        const int i = (int)((idx / K) % N);
-        const int z = (int)(idx / ((size_t)K * N));
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) s = fmaf(a[(size_t)z * a_zs + (size_t)b * a_bs + i], c[(size_t)b * K + j], s);
-        out[idx] = s;
-    }
-}
-
-// out[b][j] = sum_z sum_i W[z*w_zs + i*K + j] * a[z*a_zs + b*a_bs + i]   (transposed linears, summed over layers)
-__global__ void small_linear_t_kernel(const float *__restrict__ W, long w_zs, const float *__restrict__ a, long a_zs,
-                                      long a_bs, float *__restrict__ out, int Z, int B, int N, int K)
-{
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * K) return;
-    const int b = idx / K, j = idx - b * K;
-    float s = 0.f;
-    for (int z = 0; z < Z; ++z) {
-        const float *w = W + (size_t)z * w_zs + j;
-        const float *av = a + (size_t)z * a_zs + (size_t)b * a_bs;
-        for (int i = 0; i < N; ++i) s = fmaf(w[(size_t)i * K], av[i], s);
-    }
-    out[idx] = s;
-}
-
-// da = dm * mish'(x),  mish'(x) = tanh(sp) + x (1 - tanh(sp)^2) sigmoid(x),  sp = softplus(x)
-__global__ void mish_bwd_kernel(const float *__restrict__ dm, const float *__restrict__ x, float *__restrict__ da, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float v = x[i];
-    const float ts = tanhf(mg_softplus(v));
-    const float sg = 1.f / (1.f + expf(-v));
-    da[i] = dm[i] * (ts + v * (1.f - ts * ts) * sg);
-}
-
-// out[b,c,l] = alpha * in[b*in_bs + c*L + l] * (mask[b,c,l] > 0)
-__global__ void scale_mask_kernel(const float *__restrict__ in, long in_bs, const float *__restrict__ mask,
-                                  float *__restrict__ out, float alpha, int CL, size_t n)
-{
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t b = i / CL;
-        const size_t r = i - b * CL;
-        out[i] = mask[i] > 0.f ? alpha * in[b * in_bs + r] : 0.f;
-    }
-}
-
 // thin shim over the exported weight-gradient entry point (kernel lives in conv_api.hip)
 struct WgradShape {
     int B, Co, Ci, Ldy, Lx, K, stride, pad;

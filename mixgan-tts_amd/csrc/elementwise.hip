@@ -156,8 +156,9 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
                                                         const float *__restrict__ spec_min,
                                                         const float *__restrict__ spec_max,
                                                         const uint8_t *__restrict__ keep, int to_blm, int mode, int L,
-                                                        int M)
+                                                        int M, long bml_bs)
 {
+    // bml_bs: batch stride (floats) of the [B,M,L] side, so it may be a channel slice of a wider tensor
     extern __shared__ float tile[];  // [TL][M+1]
     const int b = blockIdx.y;
     const int l0 = blockIdx.x * TL;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
         // read [M][nl] rows of the BML tensor
         for (int idx = threadIdx.x; idx < M * TL; idx += 256) {
             const int m = idx / TL, l = idx - m * TL;
-            if (l < nl) tile[l * P + m] = in[((size_t)b * M + m) * L + l0 + l];
+            if (l < nl) tile[l * P + m] = in[(size_t)b * bml_bs + (size_t)m * L + l0 + l];
         }
         __syncthreads();
         float *dst = out + ((size_t)b * L + l0) * M;
@@ -192,20 +193,31 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
             if (l >= nl) continue;
             float v = tile[l * P + m];
             if (keep) v *= (float)keep[(size_t)b * L + l0 + l];
-            out[((size_t)b * M + m) * L + l0 + l] = v;
+            out[(size_t)b * bml_bs + (size_t)m * L + l0 + l] = v;
         }
     }
 }
 
+extern "C" int mg_transpose_bml_strided(const float *in, float *out, const float *spec_min, const float *spec_max,
+                                        const uint8_t *keep, int to_blm, int mode, int B, int L, int M, long bml_bs,
+                                        void *stream);
+
 extern "C" int mg_transpose_bml(const float *in, float *out, const float *spec_min, const float *spec_max,
                                 const uint8_t *keep, int to_blm, int mode, int B, int L, int M, void *stream)
+{
+    return mg_transpose_bml_strided(in, out, spec_min, spec_max, keep, to_blm, mode, B, L, M, 0, stream);
+}
+
+extern "C" int mg_transpose_bml_strided(const float *in, float *out, const float *spec_min, const float *spec_max,
+                                        const uint8_t *keep, int to_blm, int mode, int B, int L, int M, long bml_bs,
+                                        void *stream)
 {
     if (!in || !out) return MG_ERR_ARG;
     if (mode < 0 || mode > 2 || (mode != 0 && (!spec_min || !spec_max))) return MG_ERR_ARG;
     if (B <= 0 || L <= 0 || M <= 0 || M > 1024) return MG_ERR_SHAPE;
     dim3 grid(mg_cdiv(L, TL), B);
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), (size_t)TL * (M + 1) * sizeof(float), (hipStream_t)stream, in,
-                       out, spec_min, spec_max, keep, to_blm, mode, L, M);
+                       out, spec_min, spec_max, keep, to_blm, mode, L, M, bml_bs ? bml_bs : (long)M * L);
     MG_LAUNCH_CHECK();
     return MG_OK;
 }

@@ -26,11 +26,29 @@ def pack_conv_weight(w, mode=PACK_PLAIN):
     return out
 
 
+_PACK_CACHE = {}
+
+
+def pack_cached(w, mode=PACK_PLAIN):
+    """pack_conv_weight with a small cache keyed on (storage, version): the packed form is a derived
+    cache of the parameter and is rebuilt after every optimizer step / load_state_dict."""
+    key = (w.data_ptr(), tuple(w.shape), mode)
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] == w._version:
+        return hit[1]
+    if len(_PACK_CACHE) > 256:
+        _PACK_CACHE.clear()
+    p = pack_conv_weight(w, mode)
+    _PACK_CACHE[key] = (w._version, p)
+    return p
+
+
 def conv1d_packed(x, packed, bias, Co, K, stride=1, padding=0, act=None, alpha=1.0, add=None, in_vec=None,
-                  out=None, accumulate=False):
+                  out=None, accumulate=False, Lout=None):
     L = _lib.lib()
     B, Ci, Lin = x.shape
-    Lout = (Lin + 2 * padding - K) // stride + 1
+    if Lout is None:
+        Lout = (Lin + 2 * padding - K) // stride + 1
     if out is None:
         out = torch.empty(B, Co, Lout, device=x.device, dtype=torch.float32)
     check(L.mg_conv1d_fwd(fptr(x), fptr(in_vec, True), fptr(packed), fptr(bias, True), fptr(add, True), fptr(out),
@@ -132,3 +150,86 @@ def rowsum(x, per_batch=False, alpha=1.0):
     check(L.mg_rowsum(fptr(x), 0, B, R, Lf, fptr(None if per_batch else out, True), fptr(out if per_batch else None, True),
                       float(alpha), 0, stream_ptr()))
     return out
+
+
+def act_bwd(dy, y, act):
+    L = _lib.lib()
+    out = torch.empty_like(dy)
+    check(L.mg_act_bwd(fptr(dy), fptr(y), fptr(out), ACT[act], dy.numel(), stream_ptr()))
+    return out
+
+
+def upsample_zero(x, stride, Lup):
+    L = _lib.lib()
+    B, C, Lin = x.shape
+    out = torch.empty(B, C, Lup, device=x.device, dtype=torch.float32)
+    check(L.mg_upsample_zero(fptr(x), fptr(out), B * C, Lin, stride, Lup, stream_ptr()))
+    return out
+
+
+def cat_transpose(a, b):
+    """torch.cat([a, b], -1).transpose(1, 2) for a, b [B,L,M] -> [B,2M,L] (model/mixgantts.py:262-264)."""
+    L = _lib.lib()
+    B, Lf, M = a.shape
+    out = torch.empty(B, 2 * M, Lf, device=a.device, dtype=torch.float32)
+    for i, src in enumerate((a, b)):
+        dst = ctypes.c_void_p(out.data_ptr() + i * M * Lf * 4)
+        check(L.mg_transpose_bml_strided(fptr(src), dst, None, None, None, 0, 0, B, Lf, M, 2 * M * Lf, stream_ptr()))
+    return out
+
+
+def split_transpose(g, M):
+    """inverse of cat_transpose for gradients: g [B,2M,L] -> two [B,L,M]."""
+    L = _lib.lib()
+    B, M2, Lf = g.shape
+    outs = []
+    for i in range(2):
+        o = torch.empty(B, Lf, M, device=g.device, dtype=torch.float32)
+        src = ctypes.c_void_p(g.data_ptr() + i * M * Lf * 4)
+        check(L.mg_transpose_bml_strided(src, fptr(o), None, None, None, 1, 0, B, Lf, M, M2 * Lf, stream_ptr()))
+        outs.append(o)
+    return outs
+
+
+def step_mlp_fwd(t, freq, W0, W2):
+    L = _lib.lib()
+    B = t.shape[0]
+    D1, D0 = W0.shape
+    D2 = W2.shape[0]
+    dev = W0.device
+    emb, pre, h = (torch.empty(B, d, device=dev) for d in (D0, D1, D1))
+    out = torch.empty(B, D2, device=dev)
+    check(L.mg_step_mlp_fwd(iptr(t, torch.int64), fptr(freq), fptr(W0), fptr(W2), fptr(emb), fptr(pre), fptr(h),
+                            fptr(out), B, D0, D1, D2, stream_ptr()))
+    return out, emb, pre, h
+
+
+def step_mlp_bwd(g, emb, pre, h, W2):
+    L = _lib.lib()
+    B, D2 = g.shape
+    D0, D1 = emb.shape[1], pre.shape[1]
+    dW0 = torch.empty(D1, D0, device=g.device)
+    dW2 = torch.empty(D2, D1, device=g.device)
+    scratch = torch.empty(2 * B * D1, device=g.device)
+    check(L.mg_step_mlp_bwd(fptr(g), fptr(emb), fptr(pre), fptr(h), fptr(W2), fptr(dW0), fptr(dW2), fptr(scratch),
+                            B, D0, D1, D2, stream_ptr()))
+    return dW0, dW2
+
+
+def linear_small_fwd(x, W):
+    L = _lib.lib()
+    B, K = x.shape
+    N = W.shape[0]
+    out = torch.empty(B, N, device=x.device)
+    check(L.mg_linear_small_fwd(fptr(x), fptr(W), fptr(out), B, N, K, stream_ptr()))
+    return out
+
+
+def linear_small_bwd(g, x, W, want_dx=True):
+    L = _lib.lib()
+    B, N = g.shape
+    K = x.shape[1]
+    dx = torch.empty_like(x) if want_dx else None
+    dW = torch.empty_like(W)
+    check(L.mg_linear_small_bwd(fptr(g), fptr(x), fptr(W), fptr(dx, True), fptr(dW), B, N, K, stream_ptr()))
+    return dx, dW
