@@ -26,20 +26,19 @@ def pack_conv_weight(w, mode=PACK_PLAIN):
     return out
 
 
-_PACK_CACHE = {}
-
-
 def pack_cached(w, mode=PACK_PLAIN):
-    """pack_conv_weight with a small cache keyed on (storage, version): the packed form is a derived
-    cache of the parameter and is rebuilt after every optimizer step / load_state_dict."""
-    key = (w.data_ptr(), tuple(w.shape), mode)
-    hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0] == w._version:
+    """pack_conv_weight with the result cached ON the owning parameter object (so its lifetime is the
+    parameter's: an address-keyed cache goes stale when the allocator reuses freed storage).  The
+    packed form is a derived cache, rebuilt when the parameter's version changes (optimizer step,
+    load_state_dict)."""
+    owner = w._base if w._base is not None else w
+    cache = owner.__dict__.setdefault("_mg_pack", {})
+    key = (mode, tuple(w.shape), owner.data_ptr())
+    hit = cache.get(key)
+    if hit is not None and hit[0] == owner._version:
         return hit[1]
-    if len(_PACK_CACHE) > 256:
-        _PACK_CACHE.clear()
     p = pack_conv_weight(w, mode)
-    _PACK_CACHE[key] = (w._version, p)
+    cache[key] = (owner._version, p)
     return p
 
 
