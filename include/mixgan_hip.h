@@ -210,6 +210,20 @@ int mg_linear_small_fwd(const float *x, const float *W, float *out, int B, int N
 int mg_linear_small_bwd(const float *g, const float *x, const float *W, float *dx, float *dW, int B,
                         int N, int K, void *stream);
 
+/* ------------------------------------------------------------------ losses on the path (model/loss.py)
+ * mg_loss_sum: out[0] = sum (a-c)^2 (mode 0: F.mse_loss against a constant label, loss.py:14-19)
+ *              or sum |a-b| (mode 1: F.l1_loss numerator, loss.py:221-227); the caller divides by n.
+ * mg_loss_grad: da = g[0] * coef * {2(a-c) | sign(a-b)}; g is a device scalar (no host sync). */
+int mg_loss_sum(const float *a, const float *b, float c, int mode, size_t n, float *out, void *stream);
+int mg_loss_grad(const float *a, const float *b, float c, int mode, const float *g, float coef, size_t n,
+                 float *da, void *stream);
+/* Masked mel L1 (loss.py:229-242,255-259) over rows = B*L frames of M bins, pad uint8 [rows] (1 = pad):
+ * out2 = {sum |p-t| over counted rows, M * #counted rows}; the loss is out2[0]/out2[1]. */
+int mg_mel_l1_fwd(const float *pred, const float *targ, const uint8_t *pad, int rows, int M, float *out2,
+                  void *stream);
+int mg_mel_l1_bwd(const float *pred, const float *targ, const uint8_t *pad, int rows, int M,
+                  const float *g, const float *den, float *dpred, void *stream);
+
 /* ------------------------------------------------------------------ measurement hooks (bench.py)
  * While a session is open, mg_denoiser_fwd brackets each launch of its dominant kernel (the k=3
  * gated convolution of a residual layer) with HIP events recorded on the launch stream.

@@ -13,6 +13,7 @@ from .blocks import ConvNorm, LinearNorm, DiffusionEmbedding, Mish, ResidualBloc
 from .denoiser import Denoiser  # noqa: F401
 from .diffusion import GaussianDiffusion  # noqa: F401
 from .discriminator import JCUDiscriminator  # noqa: F401
-from . import ops, autograd  # noqa: F401
+from . import ops, autograd, losses, distributed  # noqa: F401
+from .train_step import HotPathTrainer  # noqa: F401
 
 __version__ = "0.1.0"

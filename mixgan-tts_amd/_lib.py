@@ -17,6 +17,7 @@ EXPORTS = (
     "mg_denoiser_bwd_workspace_floats", "mg_denoiser_bwd",
     "mg_profile_begin", "mg_profile_end", "mg_transpose_bml_strided", "mg_act_bwd", "mg_upsample_zero",
     "mg_step_mlp_fwd", "mg_step_mlp_bwd", "mg_linear_small_fwd", "mg_linear_small_bwd",
+    "mg_loss_sum", "mg_loss_grad", "mg_mel_l1_fwd", "mg_mel_l1_bwd",
 )
 
 
@@ -89,6 +90,10 @@ def _declare(L):
         "mg_step_mlp_bwd": (i, [vp] * 8 + [i, i, i, i, vp]),
         "mg_linear_small_fwd": (i, [vp, vp, vp, i, i, i, vp]),
         "mg_linear_small_bwd": (i, [vp, vp, vp, vp, vp, i, i, i, vp]),
+        "mg_loss_sum": (i, [vp, vp, f, i, sz, vp, vp]),
+        "mg_loss_grad": (i, [vp, vp, f, i, vp, f, sz, vp, vp]),
+        "mg_mel_l1_fwd": (i, [vp, vp, vp, i, i, vp, vp]),
+        "mg_mel_l1_bwd": (i, [vp, vp, vp, i, i, vp, vp, vp, vp]),
         "mg_profile_begin": (i, [i]),
         "mg_profile_end": (i, [vp, i]),
     }

@@ -1,0 +1,72 @@
+"""The GAN training step of train.py:91-184 for the hot path (generator = GaussianDiffusion on a
+given conditioner, discriminator = JCUDiscriminator), with the reference's quirks kept:
+
+  * D phase first: generator forward (graph built, outputs detached), D(fake), D(real), LSGAN
+    d_loss, backward, clip_grad_norm_(D, 1.0), optD.step(), then zero_grad (train.py:75-85);
+  * G phase: a SECOND generator forward (new t, new noise), D(fake)/D(real) without freezing D,
+    adv + mel L1 + lambda_fm * FM, backward, clip, optG.step(), zero_grad.  The G-phase backward
+    therefore also deposits gradients into D's parameters, which are NOT cleared before the next
+    D-phase backward (SURVEY.md section 3.1 "D-grad leak") -- reproduced.
+  * multi-GPU: gradients are all-reduced (mean) per optimizer before clipping (distributed.py).
+
+The linguistic encoder is upstream of the path: `cond` is whatever produced
+the [B, L, 256] conditioner; its gradient is returned to the caller's graph as usual.
+"""
+import torch
+
+from . import losses
+from .distributed import GradBucket
+
+
+class HotPathTrainer:
+    def __init__(self, diffusion, discriminator, train_config, model_config, extra_g_params=()):
+        self.G, self.D = diffusion, discriminator
+        oc = train_config["optimizer"]
+        self.grad_clip = oc["grad_clip_thresh"]
+        self.lambda_fm = train_config["loss"]["lambda_fm" if diffusion.model != "shallow" else "lambda_fm_shallow"]
+        self.n_layers = model_config["discriminator"]["n_layer"] + model_config["discriminator"]["n_cond_layer"]
+        g_params = list(diffusion.parameters()) + list(extra_g_params)
+        self.optG = torch.optim.Adam(g_params, lr=oc["init_lr_G"], betas=oc["betas"])       # utils/model.py:32-40
+        self.optD = torch.optim.Adam(discriminator.parameters(), lr=oc["init_lr_D"], betas=oc["betas"])
+        self.sdlG = torch.optim.lr_scheduler.ExponentialLR(self.optG, gamma=oc["gamma"])    # stepped per EPOCH
+        self.sdlD = torch.optim.lr_scheduler.ExponentialLR(self.optD, gamma=oc["gamma"])
+        self.d_loss_fn, self.g_loss_fn = losses.get_adversarial_losses_fn(train_config["loss"]["adv_loss_mode"])
+        self.bucketG = GradBucket(g_params)
+        self.bucketD = GradBucket(list(discriminator.parameters()))
+
+    def _update(self, params, bucket, opt):
+        bucket.all_reduce_mean()                      # no-op on one process
+        torch.nn.utils.clip_grad_norm_(params, self.grad_clip)
+        opt.step()
+        opt.zero_grad()                               # after step, as train.py:84-85
+
+    def step(self, mel, cond, spk, mel_pad_mask, coarse_mel=None):
+        """One D phase + one G phase on a batch.  mel [B,L,M]; cond [B,L,H]; mel_pad_mask True = pad."""
+        G, D = self.G, self.D
+        # ---------------- D phase (train.py:133-146)
+        x0, x_ts, x_prevs, x_prev_preds, t = G(mel, cond, spk, mel_pad_mask, coarse_mel)
+        x_ts_d, x_prevs_d, x_pp_d = x_ts.detach(), x_prevs.detach(), x_prev_preds.detach()
+        spk_d = spk.detach() if spk is not None else None
+        f_c, f_u = D(x_ts_d, x_pp_d, spk_d, t)
+        r_c, r_u = D(x_ts_d, x_prevs_d, spk_d, t)
+        d_real, d_fake = self.d_loss_fn(r_c[-1], r_u[-1], f_c[-1], f_u[-1])
+        d_loss = d_real + d_fake
+        d_loss.backward()
+        self._update(list(D.parameters()), self.bucketD, self.optD)
+        # ---------------- G phase (train.py:153-184)
+        x0, x_ts, x_prevs, x_prev_preds, t = G(mel, cond, spk, mel_pad_mask, coarse_mel)
+        f_c, f_u = D(x_ts, x_prev_preds, spk, t)
+        r_c, r_u = D(x_ts, x_prevs, spk, t)
+        adv = self.g_loss_fn(f_c[-1], f_u[-1])
+        target = coarse_mel.detach() if G.model == "shallow" else mel
+        mel_loss = losses.get_mel_loss(G.denorm_spec(x0), target, mel_pad_mask)
+        fm = self.lambda_fm * losses.get_fm_loss(r_c, r_u, f_c, f_u, self.n_layers)
+        g_loss = adv + mel_loss + fm
+        g_loss.backward()
+        self._update(self.bucketG.params, self.bucketG, self.optG)
+        return {"d_loss": d_loss.detach(), "adv_loss": adv.detach(), "mel_loss": mel_loss.detach(),
+                "fm_loss": fm.detach() if torch.is_tensor(fm) else fm}
+
+    def end_epoch(self):
+        self.sdlG.step()
+        self.sdlD.step()

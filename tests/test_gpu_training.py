@@ -1,0 +1,144 @@
+"""GPU parity of the losses and of the GAN training step (train.py:91-184 restricted to the hot
+path): gradients of both phases against torch.autograd on the CPU oracle with identical injected
+t / noise, plus the reference's D-gradient leak and optimizer wiring."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden, T, seeded, assert_close, hot_path_configs, write_stats, load_seeded, Tape
+from oracle import refmath as R, schedule as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mg():
+    import mixgan_tts_amd as m
+    assert torch.cuda.is_available()
+    m.lib()
+    return m
+
+
+def test_losses_golden(mg):
+    g = golden("mel_loss")
+    pred = T(g["pred"]).cuda().requires_grad_()
+    v = mg.losses.get_mel_loss(pred, T(g["targ"]).cuda(), T(g["pad"]).cuda())
+    assert abs(v.item() - float(g["loss"])) < 2e-6
+    v.backward()
+    pr = T(g["pred"]).requires_grad_()
+    R.mel_l1(pr, T(g["targ"]), T(g["pad"])).backward()
+    assert_close(pred.grad.cpu(), pr.grad, 1e-6, "mel L1 gradient")
+    # LSGAN / FM scalars + gradients vs the oracle on the fixture's feature maps
+    j = golden("jcu_ms0_L37")
+    maps = {k: [T(j["%s%d" % (k, i)]) for i in range(5)] for k in ("fc", "fu", "rc", "ru")}
+    dm = {k: [m.cuda().requires_grad_() for m in v] for k, v in maps.items()}
+    cm = {k: [m.clone().requires_grad_() for m in v] for k, v in maps.items()}
+    d_fn, g_fn = mg.losses.get_adversarial_losses_fn("lsgan")
+    r, f = d_fn(dm["rc"][-1], dm["ru"][-1], dm["fc"][-1], dm["fu"][-1])
+    adv = g_fn(dm["fc"][-1], dm["fu"][-1])
+    fm = mg.losses.get_fm_loss(dm["rc"], dm["ru"], dm["fc"], dm["fu"])
+    for a, k in ((r, "r_loss"), (f, "f_loss"), (adv, "adv"), (fm, "fm")):
+        assert abs(a.item() - float(j[k])) <= 2e-6 * max(1.0, abs(float(j[k]))), k
+    (r + f + adv + 10.0 * fm).backward()
+    rr, ff = R.d_loss(cm["rc"][-1], cm["ru"][-1], cm["fc"][-1], cm["fu"][-1])
+    (rr + ff + R.g_loss(cm["fc"][-1], cm["fu"][-1]) + 10.0 * R.fm_loss(cm["rc"], cm["ru"], cm["fc"], cm["fu"])).backward()
+    for k in ("fc", "fu"):
+        for i in range(5):
+            assert_close(dm[k][i].grad.cpu(), cm[k][i].grad, 1e-6, "%s%d grad" % (k, i))
+
+
+def _setup(mg, manifest, tmp_path, B=3, L=40):
+    e = golden("elementwise")
+    stats = write_stats(tmp_path, e["spec_min"], e["spec_max"])
+    args, pre, mc, tr = hot_path_configs("naive", 4, stats_dir=stats)
+    G = mg.GaussianDiffusion(args, pre, mc, tr)
+    load_seeded(G, manifest, "diffusion_naive_ms0", 61)
+    D = mg.JCUDiscriminator(pre, mc, tr)
+    load_seeded(D, manifest, "jcu_ms0", 62)
+    WG, _ = seeded(manifest, "diffusion_naive_ms0", 61, requires_grad=True)
+    WD, _ = seeded(manifest, "jcu_ms0", 62, requires_grad=True)
+    buf = {k: T(v) for k, v in S.diffusion_buffers(S.beta_schedule("vpsde", 4, 0.1, 40, 0.008)).items()}
+    buf["spec_min"], buf["spec_max"] = T(e["spec_min"])[None, None], T(e["spec_max"])[None, None]
+    gen = torch.Generator().manual_seed(7)
+    lens = torch.tensor([L, L - 9, L - 3])[:B]
+    pad = torch.arange(L)[None, :] >= lens[:, None]
+    mel = (torch.rand(B, L, 80, generator=gen) * 13.5 - 11.5).masked_fill(pad.unsqueeze(-1), 0.0)
+    cond = torch.randn(B, L, 256, generator=gen)
+    tapes = [[torch.tensor([2, 0, 3])[:B]] + [torch.randn(B, 1, 80, L, generator=gen) for _ in range(3)] for _ in range(2)]
+    return G.cuda(), D.cuda(), WG, WD, buf, mel, cond, pad, tapes, tr, mc
+
+
+def test_training_step_gradients_vs_oracle(mg, manifest, tmp_path):
+    G, D, WG, WD, buf, mel, cond, pad, tapes, tr, mc = _setup(mg, manifest, tmp_path)
+    lam = tr["loss"]["lambda_fm"]
+    # ---------------- oracle: D phase then G phase with torch.autograd on CPU
+    def oracle_phase(tape_items, d_phase):
+        tape = R.NoiseTape(tape_items)
+        c = cond.clone().requires_grad_()
+        x0, x_t, x_prev, x_pp, t = R.diffusion_forward(WG, buf, "naive", 4, mel, c, None, pad, None, tape)
+        if d_phase:
+            fc, fu = R.jcu_forward(WD, x_t.detach(), x_pp.detach(), None, t)
+            rc, ru = R.jcu_forward(WD, x_t.detach(), x_prev.detach(), None, t)
+            r, f = R.d_loss(rc[-1], ru[-1], fc[-1], fu[-1])
+            return r + f, c
+        fc, fu = R.jcu_forward(WD, x_t, x_pp, None, t)
+        rc, ru = R.jcu_forward(WD, x_t, x_prev, None, t)
+        loss = (R.g_loss(fc[-1], fu[-1]) + R.mel_l1(R.denorm_spec(x0, buf["spec_min"], buf["spec_max"]), mel, pad)
+                + lam * R.fm_loss(rc, ru, fc, fu))
+        return loss, c
+
+    ld, _ = oracle_phase(tapes[0], True)
+    ld.backward()
+    ref_d = {k: v.grad.clone() for k, v in WD.items()}
+    for v in list(WD.values()) + list(WG.values()):
+        v.grad = None
+    lg, c_ref = oracle_phase(tapes[1], False)
+    lg.backward()
+    ref_g = {k: v.grad.clone() for k, v in WG.items()}
+    ref_leak = {k: v.grad.clone() for k, v in WD.items()}
+
+    # ---------------- product: the same two phases, gradients inspected before the optimizers run
+    d_fn, g_fn = mg.losses.get_adversarial_losses_fn("lsgan")
+    melc, condc, padc = mel.cuda(), cond.cuda(), pad.cuda()
+    G.t_fn, G.noise_fn = Tape([tapes[0][0].numpy()]), Tape([a.numpy() for a in tapes[0][1:]])
+    x0, x_t, x_prev, x_pp, t = G(melc, condc.clone().requires_grad_(), None, padc)
+    fc, fu = D(x_t.detach(), x_pp.detach(), None, t)
+    rc, ru = D(x_t.detach(), x_prev.detach(), None, t)
+    r, f = d_fn(rc[-1], ru[-1], fc[-1], fu[-1])
+    assert abs((r + f).item() - ld.item()) < 1e-5 * max(1, abs(ld.item()))
+    (r + f).backward()
+    for k, p in D.named_parameters():
+        assert_close(p.grad.cpu(), ref_d[k], 1e-4, "D-phase grad " + k)
+    D.zero_grad()
+    G.zero_grad()
+    G.t_fn, G.noise_fn = Tape([tapes[1][0].numpy()]), Tape([a.numpy() for a in tapes[1][1:]])
+    cg = condc.clone().requires_grad_()
+    x0, x_t, x_prev, x_pp, t = G(melc, cg, None, padc)
+    fc, fu = D(x_t, x_pp, None, t)
+    rc, ru = D(x_t, x_prev, None, t)
+    loss = g_fn(fc[-1], fu[-1]) + mg.losses.get_mel_loss(G.denorm_spec(x0), melc, padc) + lam * mg.losses.get_fm_loss(rc, ru, fc, fu)
+    assert abs(loss.item() - lg.item()) < 1e-5 * max(1, abs(lg.item()))
+    loss.backward()
+    assert_close(cg.grad.cpu(), c_ref.grad, 1e-4, "G-phase d_cond")
+    for k, p in G.named_parameters():
+        assert_close(p.grad.cpu(), ref_g[k], 2e-4, "G-phase grad " + k)
+    for k, p in D.named_parameters():
+        assert_close(p.grad.cpu(), ref_leak[k], 2e-4, "leaked D grad " + k)
+
+
+def test_trainer_step_runs_and_leaks_d_grads(mg, manifest, tmp_path):
+    G, D, WG, WD, buf, mel, cond, pad, tapes, tr, mc = _setup(mg, manifest, tmp_path)
+    trainer = mg.HotPathTrainer(G, D, tr, mc)
+    before_g = [p.detach().clone() for p in G.parameters()]
+    before_d = [p.detach().clone() for p in D.parameters()]
+    out = trainer.step(mel.cuda(), cond.cuda(), None, pad.cuda())
+    assert all(torch.isfinite(v).all() for v in out.values())
+    assert any(not torch.equal(a, b) for a, b in zip(before_g, G.parameters()))
+    assert any(not torch.equal(a, b) for a, b in zip(before_d, D.parameters()))
+    # train.py:84-85 + :159-160: zero_grad runs after step, the G-phase backward then leaves gradients on D
+    assert all(p.grad is None for p in G.parameters())
+    assert all(p.grad is not None for p in D.parameters())
+    out2 = trainer.step(mel.cuda(), cond.cuda(), None, pad.cuda())
+    assert all(torch.isfinite(v).all() for v in out2.values())
+    trainer.end_epoch()
+    assert abs(trainer.optG.param_groups[0]["lr"] - 1e-4 * 0.999) < 1e-12
