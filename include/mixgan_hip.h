@@ -224,6 +224,19 @@ int mg_mel_l1_fwd(const float *pred, const float *targ, const uint8_t *pad, int 
 int mg_mel_l1_bwd(const float *pred, const float *targ, const uint8_t *pad, int rows, int M,
                   const float *g, const float *den, float *dpred, void *stream);
 
+/* ------------------------------------------------------------------ FFT blocks (shallow / aux coarse mel)
+ * Multi-head self-attention of transformer/SubLayers.py:29-57 + Modules.py:16-23 without the
+ * [n_head*B, L, L] score tensor (streaming softmax, fp32 MFMA).  qkv [B, 3*n_head*d_head, L]
+ * channel-major, rows = [Q heads | K heads | V heads], head-major like the reference's .view();
+ * key_pad uint8 [B, L] (1 = padded key, masked with -inf for every query) or NULL;
+ * out [B, n_head*d_head, L]; scale = 1/temperature = 1/sqrt(d_k).  d_head must be 128. */
+int mg_attention_fwd(const float *qkv, const uint8_t *key_pad, float *out, int B, int L, int n_head,
+                     int d_head, float scale, void *stream);
+/* Post-LayerNorm on the channel-major layout (SubLayers.py:55,91 + Layers.py:25,28):
+ * out[b,c,l] = pad[b,l] ? 0 : LN_c(a[b,:,l] + res[b,:,l]) * gamma[c] + beta[c];  C must be 256. */
+int mg_layernorm_cm_fwd(const float *a, const float *res, const float *gamma, const float *beta,
+                        const uint8_t *pad, float *out, int B, int C, int L, float eps, void *stream);
+
 /* ------------------------------------------------------------------ measurement hooks (bench.py)
  * While a session is open, mg_denoiser_fwd brackets each launch of its dominant kernel (the k=3
  * gated convolution of a residual layer) with HIP events recorded on the launch stream.

@@ -17,7 +17,7 @@ EXPORTS = (
     "mg_denoiser_bwd_workspace_floats", "mg_denoiser_bwd",
     "mg_profile_begin", "mg_profile_end", "mg_transpose_bml_strided", "mg_act_bwd", "mg_upsample_zero",
     "mg_step_mlp_fwd", "mg_step_mlp_bwd", "mg_linear_small_fwd", "mg_linear_small_bwd",
-    "mg_loss_sum", "mg_loss_grad", "mg_mel_l1_fwd", "mg_mel_l1_bwd",
+    "mg_loss_sum", "mg_loss_grad", "mg_mel_l1_fwd", "mg_mel_l1_bwd", "mg_attention_fwd", "mg_layernorm_cm_fwd",
 )
 
 
@@ -94,6 +94,8 @@ def _declare(L):
         "mg_loss_grad": (i, [vp, vp, f, i, vp, f, sz, vp, vp]),
         "mg_mel_l1_fwd": (i, [vp, vp, vp, i, i, vp, vp]),
         "mg_mel_l1_bwd": (i, [vp, vp, vp, i, i, vp, vp, vp, vp]),
+        "mg_attention_fwd": (i, [vp, vp, vp, i, i, i, i, f, vp]),
+        "mg_layernorm_cm_fwd": (i, [vp, vp, vp, vp, vp, vp, i, i, i, f, vp]),
         "mg_profile_begin": (i, [i]),
         "mg_profile_end": (i, [vp, i]),
     }

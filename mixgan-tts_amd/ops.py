@@ -232,3 +232,22 @@ def linear_small_bwd(g, x, W, want_dx=True):
     dW = torch.empty_like(W)
     check(L.mg_linear_small_bwd(fptr(g), fptr(x), fptr(W), fptr(dx, True), fptr(dW), B, N, K, stream_ptr()))
     return dx, dW
+
+
+def attention(qkv, key_pad, n_head, d_head):
+    """qkv [B, 3*n_head*d_head, L] -> [B, n_head*d_head, L] (mg_attention_fwd)."""
+    L = _lib.lib()
+    B, _, Lf = qkv.shape
+    out = torch.empty(B, n_head * d_head, Lf, device=qkv.device, dtype=torch.float32)
+    check(L.mg_attention_fwd(fptr(qkv), iptr(key_pad, torch.uint8, True), fptr(out), B, Lf, n_head, d_head,
+                             float(d_head) ** -0.5, stream_ptr()))
+    return out
+
+
+def layernorm_cm(a, res, gamma, beta, pad, eps=1e-5):
+    L = _lib.lib()
+    B, C, Lf = a.shape
+    out = torch.empty_like(a)
+    check(L.mg_layernorm_cm_fwd(fptr(a), fptr(res, True), fptr(gamma), fptr(beta), iptr(pad, torch.uint8, True),
+                                fptr(out), B, C, Lf, float(eps), stream_ptr()))
+    return out
