@@ -68,3 +68,68 @@ def test_attention_and_layernorm_vs_oracle(mg, manifest, B, L, lens):
     full = R.fft_block(W, "", x, pad)
     out, _ = blk(x.cuda(), mask=pad.cuda())
     assert_close(out.cpu(), full, TOL, "FFT block")
+
+
+class _StubEncoder(torch.nn.Module):
+    """Stands in for the out-of-scope LinguisticEncoder: returns a fixed conditioner and the masks."""
+
+    def __init__(self, cond):
+        super().__init__()
+        self.cond = cond
+
+    def forward(self, texts, src_lens, word_boundaries, src_masks, src_w_lens, src_w_masks, mel_masks, max_mel_len,
+                attn_priors, p_targets, e_targets, d_targets, p_control, d_control):
+        lens = (mel_masks).sum(1)
+        return self.cond, None, None, None, None, lens, mel_masks, None, None
+
+
+@pytest.mark.parametrize("model", ["naive", "shallow"])
+def test_mixgantts_forward_inference_vs_oracle(mg, manifest, tmp_path, model):
+    """MixGANTTS.forward (model/mixgantts.py:55-180) with an injected conditioner: output-list layout and the
+    final mel against the oracle chain (coarse mel -> shallow diffusion / naive sampling)."""
+    from helpers import write_stats, Tape
+    from oracle import schedule as S
+    e = golden("elementwise")
+    stats = write_stats(tmp_path, e["spec_min"], e["spec_max"])
+    args, pre, mc, tr = hot_path_configs(model, 4, stats_dir=stats, max_seq_len=1000)
+    gen = torch.Generator().manual_seed(11)
+    B, L = 2, 70
+    cond = torch.randn(B, L, 256, generator=gen)
+    mel_lens = torch.tensor([70, 51])
+    net = mg.MixGANTTS(args, pre, mc, tr, linguistic_encoder=_StubEncoder(cond.cuda()))
+    W = {}
+    if model == "shallow":
+        for name, mod, seed, pfx in (("decoder", net.decoder, 71, "decoder."), ("postnet", net.postnet, 72, "postnet.")):
+            _, pre2, mc2, _ = hot_path_configs(stats_dir=".", max_seq_len=48)
+            man = dict(manifest)
+            if name == "decoder":   # fixture manifest was recorded at max_seq_len=48; only trainable shapes matter
+                pass
+            load_seeded(mod, man, name, seed)
+            w, _ = seeded(man, name, seed, prefix=pfx)
+            W.update(w)
+        W["decoder.position_enc"] = R.sinusoid_table(1001, 256)[None]
+        with torch.no_grad():
+            net.mel_linear.weight.copy_(torch.randn(80, 256, generator=gen) / 16)
+            net.mel_linear.bias.copy_(torch.randn(80, generator=gen) * 0.1)
+        W["mel_linear.weight"], W["mel_linear.bias"] = net.mel_linear.weight.detach().clone(), net.mel_linear.bias.detach().clone()
+    load_seeded(net.diffusion, manifest, "diffusion_naive_ms0", 73)
+    Wd, _ = seeded(manifest, "diffusion_naive_ms0", 73)
+    net = net.cuda().eval()
+    n_noise = 5 if model == "naive" else 5
+    noises = [torch.randn(B, 1, 80, L, generator=gen) for _ in range(n_noise)]
+    net.diffusion.noise_fn = Tape([n.numpy() for n in noises])
+    z = torch.zeros(B, 5, dtype=torch.long).cuda()
+    with torch.no_grad():
+        out, p_t, coarse = net(None, z, torch.tensor([5, 5]).cuda(), 5, None, torch.tensor([3, 3]).cuda(), 3,
+                               mels=None, mel_lens=mel_lens.cuda(), max_mel_len=L)
+    assert len(out) == 16 and out[1] == (None, None, None)
+    pad = torch.arange(L)[None, :] >= mel_lens[:, None]
+    assert torch.equal(out[9].cpu(), pad)                       # slot 9: mel_masks, True = pad
+    buf = {k: T(v) for k, v in S.diffusion_buffers(S.beta_schedule("vpsde", 4, 0.1, 40, 0.008)).items()}
+    buf["spec_min"], buf["spec_max"] = T(e["spec_min"])[None, None], T(e["spec_max"])[None, None]
+    coarse_ref = R.coarse_mel(W, cond, pad, 1000) if model == "shallow" else None
+    ref, *_ = R.diffusion_forward(Wd, buf, model, 4, None, cond, None, pad, coarse_ref, R.NoiseTape(noises))
+    if model == "shallow":
+        assert_close(coarse.cpu(), coarse_ref, 5e-5, "coarse mel")
+        assert_close(out[15].cpu(), coarse_ref, 5e-5, "postnet_outputs slot")
+    assert_close(out[0].cpu(), ref, 1e-4, "final mel")
