@@ -113,13 +113,19 @@ class GaussianDiffusion(nn.Module):
         return ops.posterior_sample(x0, x, t.contiguous(), noise, None, self._buf(), clip=clip_denoised)[:, None]
 
     @torch.no_grad()
-    def sampling(self, noise=None, keep_trace=True):
+    def sampling(self, noise=None, keep_trace=True, use_graph=False):
         """Reverse process from the stashed cond/spk (model/diffusion.py:155-165).
-        Returns the list of denormalised mels [B,L,M] (T+1 entries, or only the last)."""
+        Returns the list of denormalised mels [B,L,M] (T+1 entries, or only the last).
+        use_graph=True replays the whole T-step loop as one captured hipGraph (static shapes, t read
+        from device memory, on-device RNG); it implies keep_trace=False and ignores `noise_fn`."""
         cond = self.cond
         B, _, L = cond.shape
         dev = cond.device
         M, T = self.mel_bins, self.num_timesteps
+        if use_graph and self.noise_fn is None:
+            x = self._bml(torch.randn((B, 1, M, L), device=dev) if noise is None else noise)
+            x = self._sampling_graph(x, cond, self.spk_emb)
+            return [ops.transpose_bml(x, True, 2, self.spec_min, self.spec_max)]
         buf = self._buf()
         den = self.denoise_fn
         packed = den.packed_weights()
@@ -135,6 +141,55 @@ class GaussianDiffusion(nn.Module):
                 xs.append(x)
         outs = xs if keep_trace else [x]
         return [ops.transpose_bml(a, True, 2, self.spec_min, self.spec_max) for a in outs]
+
+    def _sampling_graph(self, x_start, cond, spk):
+        """The T-step p_sample loop as one hipGraph: captured once per (B, L, T, device) on a side
+        stream, replayed with new contents in the static x / cond / spk buffers."""
+        B, M, L = x_start.shape
+        dev = x_start.device
+        T = self.num_timesteps
+        den = self.denoise_fn
+        packed = den.packed_weights()
+        key = (B, L, T, dev, packed.data_ptr(), den._packed_key)
+        g = getattr(self, "_graph", None)
+        if g is None or g["key"] != key:
+            buf = self._buf()
+            st = {"key": key, "x": [torch.empty_like(x_start), torch.empty_like(x_start)],
+                  "x0": torch.empty_like(x_start), "noise": torch.empty_like(x_start),
+                  "cond": torch.empty_like(cond), "spk": None if spk is None else torch.empty_like(spk),
+                  "ts": [torch.full((B,), i, device=dev, dtype=torch.long) for i in range(T)]}
+            st["cond"].copy_(cond)
+            if spk is not None:
+                st["spk"].copy_(spk)
+            st["x"][0].copy_(x_start)
+
+            def loop():
+                cur = 0
+                for i in reversed(range(T)):
+                    den.run(st["x"][cur], st["ts"][i], st["cond"], st["spk"], out=st["x0"], packed=packed)
+                    st["noise"].normal_()
+                    ops.posterior_sample(st["x0"], st["x"][cur], st["ts"][i], st["noise"], None, buf, clip=True,
+                                         out=st["x"][cur ^ 1])
+                    cur ^= 1
+                return cur
+
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                loop()                                  # warm-up: workspaces allocated outside capture
+            torch.cuda.current_stream(dev).wait_stream(side)
+            st["x"][0].copy_(x_start)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                st["final"] = loop()
+            st["graph"] = graph
+            self._graph = g = st
+        g["cond"].copy_(cond)
+        if spk is not None:
+            g["spk"].copy_(spk)
+        g["x"][0].copy_(x_start)
+        g["graph"].replay()
+        return g["x"][g["final"]].clone()
 
     def diffuse_trace(self, x_start, mask):
         """aux only (model/diffusion.py:167-175): mask True = pad."""

@@ -223,3 +223,35 @@ def test_sampling_properties_full_size(mg, manifest, tmp_path):
     one = run(slice(5, 6))
     assert torch.equal(one[0], full[5])
     assert torch.isfinite(full).all()
+
+
+def test_sampling_hipgraph_matches_eager(mg, manifest, tmp_path):
+    """The captured T-step loop (cfg 3 path) against the eager loop.  With the posterior noise switched
+    off (log-variance -> -inf, so sigma = 0) both are deterministic and must agree bit for bit; with noise
+    on, the replayed graph must draw fresh noise on every replay."""
+    gd = _gd(mg, tmp_path, T_=4).cpu()
+    load_seeded(gd, manifest, "diffusion_naive_ms0", 31)
+    gd = gd.cuda().eval()
+    B, L = 3, 200
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    cond = torch.randn(B, L, 256, device="cuda", generator=gen)
+    x_T = torch.randn(B, 1, 80, L, device="cuda", generator=gen)
+    pad = torch.zeros(B, L, dtype=torch.bool, device="cuda")
+    with torch.no_grad():
+        gd(None, cond, None, pad)                       # stashes cond
+    saved = gd.posterior_log_variance_clipped.clone()
+    gd.posterior_log_variance_clipped.fill_(-1.0e4)     # exp(0.5 * -1e4) == 0
+    eager = gd.sampling(noise=x_T, keep_trace=False)[0]
+    graphed = gd.sampling(noise=x_T, keep_trace=False, use_graph=True)[0]
+    again = gd.sampling(noise=x_T, keep_trace=False, use_graph=True)[0]       # replay of the cached graph
+    assert torch.equal(eager, graphed) and torch.equal(graphed, again)
+    # a different conditioner through the same captured graph
+    cond2 = torch.randn(B, L, 256, device="cuda", generator=gen)
+    with torch.no_grad():
+        gd(None, cond2, None, pad)
+    assert torch.equal(gd.sampling(noise=x_T, keep_trace=False), gd.sampling(noise=x_T, keep_trace=False, use_graph=True))
+    gd.posterior_log_variance_clipped.copy_(saved)
+    gd._graph = None                                    # buffers changed: recapture
+    a = gd.sampling(noise=x_T, keep_trace=False, use_graph=True)[0]
+    b = gd.sampling(noise=x_T, keep_trace=False, use_graph=True)[0]
+    assert torch.isfinite(a).all() and not torch.equal(a, b)
