@@ -249,7 +249,8 @@ def test_sampling_hipgraph_matches_eager(mg, manifest, tmp_path):
     cond2 = torch.randn(B, L, 256, device="cuda", generator=gen)
     with torch.no_grad():
         gd(None, cond2, None, pad)
-    assert torch.equal(gd.sampling(noise=x_T, keep_trace=False), gd.sampling(noise=x_T, keep_trace=False, use_graph=True))
+    assert torch.equal(gd.sampling(noise=x_T, keep_trace=False)[0],
+                       gd.sampling(noise=x_T, keep_trace=False, use_graph=True)[0])
     gd.posterior_log_variance_clipped.copy_(saved)
     gd._graph = None                                    # buffers changed: recapture
     a = gd.sampling(noise=x_T, keep_trace=False, use_graph=True)[0]
