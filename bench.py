@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--frames", type=int, default=L_FRAMES)
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -77,6 +78,7 @@ def main():
             p.copy_(torch.randn(p.shape, generator=gen) * (fan ** -0.5 if p.dim() > 1 else 0.1))
     gd = gd.to(dev).eval()
     den = gd.denoise_fn
+    den.precision = args.precision
     rng = np.random.default_rng(1234 + rank)
     cond = torch.from_numpy(rng.standard_normal((B, 256, L)).astype(np.float32)).to(dev)
     x = torch.from_numpy(rng.standard_normal((B, MEL, L)).astype(np.float32)).to(dev)

@@ -159,12 +159,17 @@ typedef struct {
 #define MG_DEN_HEAD_PTRS 8
 #define MG_DEN_LAYER_PTRS 9
 
-/* with_backward != 0 also packs the transposed (data-gradient) forms mg_denoiser_bwd consumes. */
-size_t mg_denoiser_packed_floats(const mg_denoiser_dims *d, int with_backward);
+/* flags for mg_denoiser_packed_floats / mg_denoiser_pack */
+#define MG_DEN_BACKWARD 1 /* also pack the transposed (data-gradient) forms mg_denoiser_bwd consumes */
+#define MG_DEN_SPLIT 2    /* also pack hi/lo bf16 pairs for the split-precision forward */
+/* flags for mg_denoiser_fwd's `mode` */
+#define MG_FWD_SAVE 1     /* keep per-layer activations for mg_denoiser_bwd (fp32 path only) */
+#define MG_FWD_SPLIT 2    /* residual-layer GEMMs as 3-term bf16-split MFMA products (fp32-grade, ~1e-5) */
+size_t mg_denoiser_packed_floats(const mg_denoiser_dims *d, int flags);
 /* freq: the C/2 step-embedding frequencies exp(-i ln(1e4)/(C/2-1)) (model/blocks.py:909-910),
  * computed by the host exactly as the reference does and cached in the packed blob. */
 int mg_denoiser_pack(const mg_denoiser_dims *d, const float *const *weights, const float *freq,
-                     float *packed, int with_backward, void *stream);
+                     float *packed, int flags, void *stream);
 /* Workspace (floats) for a forward of batch B, L frames.  save_for_backward additionally keeps the
  * per-layer activations that mg_denoiser_bwd consumes. */
 size_t mg_denoiser_workspace_floats(const mg_denoiser_dims *d, int B, int L, int save_for_backward);
@@ -173,8 +178,7 @@ size_t mg_denoiser_workspace_floats(const mg_denoiser_dims *d, int B, int L, int
  * spk [B, H] or NULL -> out [B, M, L].  */
 int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, const float *x_t,
                     const int64_t *t, const float *cond, const float *spk, float *out,
-                    float *workspace, size_t workspace_floats, int B, int L, int save_for_backward,
-                    void *stream);
+                    float *workspace, size_t workspace_floats, int B, int L, int mode, void *stream);
 
 /* Backward of Denoiser.forward (what torch.autograd does for the reference).  `workspace` is the
  * forward's workspace of a save_for_backward call on the same inputs; `bwd_workspace` has

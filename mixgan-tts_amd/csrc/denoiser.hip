@@ -10,6 +10,7 @@
 // a running fp32 sum is kept instead.
 #include "denoiser_common.h"
 #include "resblock_fused.h"
+#include "resblock_split.h"
 #include <cstdlib>
 
 // ------------------------------------------------------------------------------------------ epilogues
@@ -130,10 +131,11 @@ struct EpiResSkip {
 };
 
 // ------------------------------------------------------------------------------------------ packing
-extern "C" size_t mg_denoiser_packed_floats(const mg_denoiser_dims *d, int with_backward)
+extern "C" size_t mg_denoiser_packed_floats(const mg_denoiser_dims *d, int flags)
 {
     if (den_check(d) != MG_OK) return 0;
-    return den_layout(d, with_backward).total;
+    if ((flags & MG_DEN_SPLIT) && (d->channels != RB_C || d->cond_channels != RB_C)) return 0;
+    return den_layout(d, flags).total;
 }
 
 static int copy_d2d(float *dst, const float *src, size_t n, hipStream_t st)
@@ -144,13 +146,14 @@ static int copy_d2d(float *dst, const float *src, size_t n, hipStream_t st)
 }
 
 extern "C" int mg_denoiser_pack(const mg_denoiser_dims *d, const float *const *w, const float *freq, float *packed,
-                                int with_backward, void *stream)
+                                int flags, void *stream)
 {
     MG_TRY(den_check(d));
     if (!w || !packed || !freq) return MG_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int C = d->channels, H = d->cond_channels, M = d->mel_bins;
-    const DenLayout o = den_layout(d, with_backward);
+    const int with_backward = flags & MG_DEN_BACKWARD;
+    const DenLayout o = den_layout(d, flags);
     for (int i = 0; i < MG_DEN_HEAD_PTRS; ++i)
         if (!w[i]) return MG_ERR_ARG;
     MG_TRY(copy_d2d(packed + o.freq, freq, C / 2, st));
@@ -188,6 +191,24 @@ extern "C" int mg_denoiser_pack(const mg_denoiser_dims *d, const float *const *w
             MG_TRY(mg_conv_pack_at(lw[3], packed + o.wc_allT, C, H, 1, MG_PACK_DGRAD, l * (C / 8), Qtot, stream));
             MG_TRY(mg_conv_pack(lw[0], bp + o.bl_w3T, 2 * C, C, 3, MG_PACK_DGRAD, stream));
             MG_TRY(mg_conv_pack(lw[5], bp + o.bl_woT, 2 * C, C, 1, MG_PACK_DGRAD, stream));
+        }
+    }
+    if (flags & MG_DEN_SPLIT) {
+        if (C != RB_C || H != RB_C) return MG_ERR_SHAPE;
+        for (int l = 0; l < d->n_layers; ++l) {
+            const float *const *lw = w + MG_DEN_HEAD_PTRS + (size_t)l * MG_DEN_LAYER_PTRS;
+            float *sp = packed + o.slayers + (size_t)l * o.slayer_stride;
+            auto pk = [&](const float *src, size_t off, int Co, int Ci, int K, int gate) {
+                const int MB = Co / 32;
+                const size_t total = (size_t)MB * K * (Ci / 16) * 64 * 8;
+                const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+                hipLaunchKernelGGL(pack_split_kernel, dim3(blocks), dim3(256), 0, st, src,
+                                   reinterpret_cast<__bf16 *>(sp + off), Co, Ci, K, MB, gate);
+            };
+            pk(lw[3], o.sl_wc, C, H, 1, 0);
+            pk(lw[0], o.sl_w3, 2 * C, C, 3, 1);
+            pk(lw[5], o.sl_wo, 2 * C, C, 1, 0);
+            MG_LAUNCH_CHECK();
         }
     }
     return MG_OK;
@@ -246,8 +267,11 @@ static inline void prof_mark(hipStream_t st, int which)
 // ------------------------------------------------------------------------------------------ forward
 extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, const float *x_t, const int64_t *t,
                                const float *cond, const float *spk, float *out, float *ws, size_t ws_floats, int B,
-                               int L, int save, void *stream)
+                               int L, int mode, void *stream)
 {
+    const int save = mode & MG_FWD_SAVE;
+    const int split = mode & MG_FWD_SPLIT;
+    if (split && save) return MG_ERR_ARG;  // the backward consumes fp32 activations
     MG_TRY(den_check(d));
     if (!packed || !x_t || !t || !cond || !out || !ws) return MG_ERR_ARG;
     if (d->multi_speaker && !spk) return MG_ERR_ARG;
@@ -256,7 +280,7 @@ extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, c
     if (ws_floats < w.total) return MG_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int C = d->channels, H = d->cond_channels, M = d->mel_bins, NL = d->n_layers;
-    const DenLayout o = den_layout(d, 0);
+    const DenLayout o = den_layout(d, split ? MG_DEN_SPLIT : 0);
     const float *lay0 = packed + o.layers;
 
     // step embedding -> MLP -> per-layer projections (model/modules.py:433-434, blocks.py:1159)
@@ -279,7 +303,41 @@ extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, c
     }
     static const bool force_generic = std::getenv("MG_DENOISER_GENERIC") != nullptr;
     const bool fused = !force_generic && C == RB_C && H == RB_C;
-    if (fused) {
+    if (split) {
+        if (C != RB_C || H != RB_C) return MG_ERR_SHAPE;
+        // conditioner -> frame-major bf16 hi/lo planes (once per call; every layer's tile stages from it)
+        __bf16 *condS = reinterpret_cast<__bf16 *>(ws + w.conds);
+        hipLaunchKernelGGL(cond_split_kernel, dim3(mg_cdiv(L, 64), B), dim3(256), 0, st, cond, condS, L);
+        MG_LAUNCH_CHECK();
+        float *xa = ws + w.x0, *xb = ws + w.y, *xc = ws + w.x;
+        for (int l = 0; l < NL; ++l) {
+            const float *lp = lay0 + (size_t)l * o.layer_stride;
+            const float *sp = packed + o.slayers + (size_t)l * o.slayer_stride;
+            ResSplitArgs a;
+            a.condS = condS;
+            a.x_in = xa;
+            a.x_out = xb;
+            a.skip = ws + w.skip;
+            a.wc = reinterpret_cast<const __bf16 *>(sp + o.sl_wc);
+            a.w3 = reinterpret_cast<const __bf16 *>(sp + o.sl_w3);
+            a.wo = reinterpret_cast<const __bf16 *>(sp + o.sl_wo);
+            a.bc = lp + o.l_bc;
+            a.b3 = lp + o.l_b3;
+            a.bo = lp + o.l_bo;
+            a.hvec = ws + w.hvec + (size_t)l * B * C;
+            a.dvec = ws + w.dvec + (size_t)l * B * C;
+            a.L = L;
+            a.tiles_per_b = mg_cdiv(L, RB_NT);
+            a.first = (l == 0);
+            prof_mark(st, 0);
+            hipLaunchKernelGGL(resblock_split_kernel, dim3((unsigned)(a.tiles_per_b * B)), dim3(512), 0, st, a);
+            prof_mark(st, 1);
+            MG_LAUNCH_CHECK();
+            float *tmp = (l == 0) ? xc : xa;
+            xa = xb;
+            xb = tmp;
+        }
+    } else if (fused) {
         // one launch per layer (resblock_fused.h); x ping-pongs between ws.x and ws.y
         const bool vec4 = (L % 4 == 0) && (((uintptr_t)cond & 15) == 0);
         float *xa = ws + w.x0, *xb = ws + w.y, *xc = ws + w.x;  // x0 is preserved when saving

@@ -117,7 +117,7 @@ extern "C" int mg_denoiser_bwd(const mg_denoiser_dims *d, const float *packed, c
     if (d->multi_speaker && !spk) return MG_ERR_ARG;
     if (B <= 0 || L <= 0) return MG_ERR_SHAPE;
     const int C = d->channels, H = d->cond_channels, M = d->mel_bins, NL = d->n_layers;
-    const DenLayout o = den_layout(d, 1);
+    const DenLayout o = den_layout(d, MG_DEN_BACKWARD);
     const DenWs w = den_ws(d, B, L, 1);
     const DenBws bw = den_bws(d, B, L);
     if (bws_floats < bw.total) return MG_ERR_WORKSPACE;

@@ -12,11 +12,14 @@ struct DenLayout {
     // backward section (data-gradient packs), present when with_backward
     size_t bw, in_wT, skip_wT, out_wT, wc_allT, blayers, blayer_stride;
     size_t bl_w3T, bl_woT;
+    // split-bf16 section (resblock_split.h), present when flags & MG_DEN_SPLIT
+    size_t slayers, slayer_stride, sl_wc, sl_w3, sl_wo;
     size_t total;
 };
 
-static inline DenLayout den_layout(const mg_denoiser_dims *d, int with_backward)
+static inline DenLayout den_layout(const mg_denoiser_dims *d, int flags)
 {
+    const int with_backward = flags & MG_DEN_BACKWARD;
     const int C = d->channels, H = d->cond_channels, M = d->mel_bins, NL = d->n_layers;
     DenLayout o;
     size_t p = 0;
@@ -74,6 +77,22 @@ static inline DenLayout den_layout(const mg_denoiser_dims *d, int with_backward)
         o.blayer_stride = r;
         p += r * NL;
     }
+    o.slayers = o.slayer_stride = o.sl_wc = o.sl_w3 = o.sl_wo = 0;
+    if (flags & MG_DEN_SPLIT) {
+        // hi/lo bf16 pairs: 32 B per lane per 16-deep k-group = MB * KG * 512 floats
+        o.slayers = p;
+        size_t r = 0;
+        auto stake = [&](size_t n) {
+            size_t at = r;
+            r += mg_align_up(n, 64);
+            return at;
+        };
+        o.sl_wc = stake((size_t)(C / 32) * (H / 16) * 512);
+        o.sl_w3 = stake((size_t)(2 * C / 32) * (3 * C / 16) * 512);
+        o.sl_wo = stake((size_t)(2 * C / 32) * (C / 16) * 512);
+        o.slayer_stride = r;
+        p += r * NL;
+    }
     o.total = p;
     return o;
 }
@@ -89,7 +108,7 @@ static inline int den_check(const mg_denoiser_dims *d)
 
 // ------------------------------------------------------------------------------------------ forward workspace
 struct DenWs {
-    size_t emb, h1pre, h1, s, dvec, hvec, x, skip, y, x0, h, g, sig, tnh, total;
+    size_t emb, h1pre, h1, s, dvec, hvec, x, skip, y, x0, h, g, sig, tnh, conds, total;
     size_t act_stride;  // per-layer stride of h/g/sig/tnh (0 when not saving)
 };
 
@@ -120,6 +139,7 @@ static inline DenWs den_ws(const mg_denoiser_dims *d, int B, int L, int save)
     w.g = take(act * nact);
     w.sig = save ? take(act * nact) : 0;
     w.tnh = save ? take(act * nact) : 0;
+    w.conds = take(act);  // frame-major bf16 hi/lo planes of the conditioner (split-precision path)
     w.total = p;
     return w;
 }

@@ -43,6 +43,10 @@ class Denoiser(nn.Module):
         self._ws = {}
         self._bws = {}
         self._save_gen = 0
+        # "fp32": exact fp32 MFMA everywhere.  "bf16x3": inference-only forward whose residual-layer
+        # GEMMs run as 3-term bf16-split products on the bf16 MFMA (fp32-grade, ~1e-5 relative);
+        # grad-enabled forwards always take the fp32 path (the backward consumes fp32 activations).
+        self.precision = "fp32"
 
     # ------------------------------------------------------------------ packed-weight cache
     def _weight_table(self):
@@ -60,9 +64,13 @@ class Denoiser(nn.Module):
 
     def packed_weights(self, with_backward=False):
         """The MFMA-ordered weight blob: a derived cache, rebuilt when any parameter changes
-        (optimizer step, load_state_dict, .to()).  with_backward adds the transposed packs."""
+        (optimizer step, load_state_dict, .to()).  with_backward adds the transposed packs,
+        precision == "bf16x3" the hi/lo bf16 packs."""
         table = self._weight_table()
-        with_backward = bool(with_backward) or (self._packed_key is not None and self._packed_key[0])
+        if self.precision not in ("fp32", "bf16x3"):
+            raise ValueError("Denoiser.precision must be 'fp32' or 'bf16x3'")
+        prev = self._packed_key[0] if self._packed_key is not None else 0
+        with_backward = (1 if with_backward else 0) | (prev & 1) | (2 if self.precision == "bf16x3" else 0) | (prev & 2)
         key = (with_backward,) + tuple((p.data_ptr(), p._version) for p in table if p is not None)
         if self._packed is None or key != self._packed_key:
             L = _lib.lib()
@@ -101,9 +109,10 @@ class Denoiser(nn.Module):
             self._save_gen += 1
         if out is None:
             out = torch.empty_like(x_t)
+        mode = 1 if save else (2 if self.precision == "bf16x3" else 0)
         check(_lib.lib().mg_denoiser_fwd(ctypes.byref(self._dims), fptr(packed), fptr(x_t), iptr(t, torch.int64),
                                          fptr(cond), fptr(spk, not self.multi_speaker), fptr(out), fptr(ws),
-                                         ws.numel(), B, L, int(save), stream_ptr()))
+                                         ws.numel(), B, L, mode, stream_ptr()))
         return out
 
     def forward(self, mel, diffusion_step, conditioner, speaker_emb, mask=None):

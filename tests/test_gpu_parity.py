@@ -256,3 +256,35 @@ def test_sampling_hipgraph_matches_eager(mg, manifest, tmp_path):
     a = gd.sampling(noise=x_T, keep_trace=False, use_graph=True)[0]
     b = gd.sampling(noise=x_T, keep_trace=False, use_graph=True)[0]
     assert torch.isfinite(a).all() and not torch.equal(a, b)
+
+
+@pytest.mark.parametrize("ms", [0, 1])
+def test_denoiser_split_bf16_precision(mg, manifest, tmp_path, ms):
+    """precision='bf16x3': the residual-layer GEMMs as 3-term bf16-split MFMA products.  Held to 2e-4
+    against the reference fixture and the oracle at ragged sizes (north_star budget: 1e-3)."""
+    name = "denoiser_ms%d" % ms
+    g = golden(name)
+    _, pre, mc, _ = hot_path_configs(multi_speaker=bool(ms), stats_dir=str(tmp_path))
+    den = mg.Denoiser(pre, mc)
+    load_seeded(den, manifest, name, 21 + ms)
+    den = den.cuda()
+    den.precision = "bf16x3"
+    with torch.no_grad():
+        out = den(dev(g["x"]), dev(g["t"]), dev(g["cond"]), dev(g["spk"]) if ms else None)
+    assert_close(out.cpu(), g["out"], 2e-4, "Denoiser.forward bf16x3")
+    if ms:
+        return
+    W, _ = seeded(manifest, name, 21)
+    gen = torch.Generator().manual_seed(3)
+    for B, L in [(1, 1), (3, 129), (2, 1000)]:
+        x = torch.randn(B, 1, 80, L, generator=gen)
+        cond = torch.randn(B, 256, L, generator=gen)
+        t = torch.randint(0, 1000, (B,), generator=gen)
+        with torch.no_grad():
+            ref = R.denoiser_forward(W, "", x, t, cond, None)
+            out = den(x.cuda(), t.cuda(), cond.cuda(), None)
+        assert_close(out.cpu(), ref, 2e-4, "bf16x3 denoiser B=%d L=%d" % (B, L))
+    # a grad-enabled forward silently keeps the exact fp32 path
+    x = dev(g["x"]).requires_grad_()
+    out = den(x, dev(g["t"]), dev(g["cond"]), None)
+    assert_close(out.detach().cpu(), g["out"], TOL, "grad-enabled forward stays fp32")

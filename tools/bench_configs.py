@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Secondary measurements for DESIGN.md (not the driver's bench): the other BASELINE.json configs
+on one MI355X.  Prints one JSON line per config."""
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import mixgan_tts_amd as mg
+from helpers import hot_path_configs, write_stats
+
+
+def seeded_(module, seed):
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for p in module.parameters():
+            if not p.requires_grad:
+                continue
+            fan = p[0].numel() if p.dim() > 1 else 1
+            p.copy_(torch.randn(p.shape, generator=gen) * (fan ** -0.5 if p.dim() > 1 else 0.1))
+
+
+def timeit(fn, warm, iters):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    d = tempfile.mkdtemp()
+    stats = write_stats(d, [-11.5] * 80, [2.0] * 80, n_speakers=218)
+    out = []
+    # cfg1-shape / cfg2-shape inference steps, eager vs graph
+    for name, model, T, B, L in (("cfg1 naive T=4 B=4 L=256", "naive", 4, 4, 256),
+                                 ("cfg2 naive T=4 B=16 L=1000", "naive", 4, 16, 1000),
+                                 ("cfg3 shallow T=100 B=32 L=1000", "shallow", 100, 32, 1000)):
+        gd = mg.GaussianDiffusion(*hot_path_configs(model, T, stats_dir=stats))
+        seeded_(gd, 1)
+        gd = gd.to(dev).eval()
+        cond = torch.randn(B, L, 256, device=dev)
+        pad = torch.zeros(B, L, dtype=torch.bool, device=dev)
+        coarse = (torch.rand(B, L, 80, device=dev) * 13.5 - 11.5) if model == "shallow" else None
+        with torch.no_grad():
+            gd(None, cond, None, pad, coarse)
+        iters = 3 if T >= 100 else 20
+        te = timeit(lambda: gd.sampling(keep_trace=False), 1, iters)
+        tg = timeit(lambda: gd.sampling(keep_trace=False, use_graph=True), 2, iters)
+        out.append({"config": name, "sampling_eager_ms": round(te * 1e3, 3), "sampling_hipgraph_ms": round(tg * 1e3, 3),
+                    "denoiser_steps_per_s_eager": round(T / te, 1), "denoiser_steps_per_s_graph": round(T / tg, 1),
+                    "tflops_graph": round(23805952.0 * B * L * T / tg / 1e12, 1)})
+        print(json.dumps(out[-1]), flush=True)
+        del gd
+        torch.cuda.empty_cache()
+    # cfg4-shape training step per GPU: multi-speaker naive, B=8, L=1000 (global 64 over 8 GPUs)
+    for name, ms, B, L in (("cfg4 per-GPU shard: multi-speaker naive train step B=8 L=1000", True, 8, 1000),
+                           ("train step B=16 L=1000 single speaker", False, 16, 1000)):
+        args, pre, mc, tr = hot_path_configs("naive", 4, multi_speaker=ms, stats_dir=stats)
+        G = mg.GaussianDiffusion(args, pre, mc, tr)
+        D = mg.JCUDiscriminator(pre, mc, tr)
+        seeded_(G, 2)
+        G, D = G.to(dev), D.to(dev)
+        trainer = mg.HotPathTrainer(G, D, tr, mc)
+        mel = torch.rand(B, L, 80, device=dev) * 13.5 - 11.5
+        cond = torch.randn(B, L, 256, device=dev)
+        spk = torch.randn(B, 256, device=dev) if ms else None
+        pad = torch.zeros(B, L, dtype=torch.bool, device=dev)
+        ts = timeit(lambda: trainer.step(mel, cond, spk, pad), 2, 5)
+        # per step: 2 denoiser fwd + 1 bwd (= 4 fwd-equivalents) + 4 D fwd + 2 D bwd passes
+        flop = (4 * 23805952.0 + 8 * 645504.0) * B * L
+        out.append({"config": name, "train_step_ms": round(ts * 1e3, 2), "train_steps_per_s": round(1 / ts, 2),
+                    "approx_tflops": round(flop / ts / 1e12, 1)})
+        print(json.dumps(out[-1]), flush=True)
+        del G, D, trainer
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
