@@ -11,6 +11,7 @@
 #include "denoiser_common.h"
 #include "resblock_fused.h"
 #include "resblock_split.h"
+#include "pointwise_fused.h"
 #include <cstdlib>
 
 // ------------------------------------------------------------------------------------------ epilogues
@@ -295,14 +296,18 @@ extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, c
         MG_TRY(small_linear(lay0 + o.l_wp, (long)o.layer_stride, spk, ws + w.hvec, (long)B * C, ws + w.dvec,
                             (long)B * C, nullptr, B, C, H, NL, 0, st));
 
+    static const bool force_generic = std::getenv("MG_DENOISER_GENERIC") != nullptr;
+    const bool fused = !force_generic && C == RB_C && H == RB_C;
     // input projection + ReLU (model/modules.py:430-431; the second relu is idempotent)
-    {
+    if (fused && M <= 96) {
+        HeadArgs ha{x_t, packed + o.in_w, packed + o.in_b, ws + w.x0, M, L, mg_cdiv(L, RB_NT)};
+        hipLaunchKernelGGL(denoiser_head_kernel, dim3((unsigned)(ha.tiles_per_b * B)), dim3(512), 0, st, ha);
+        MG_LAUNCH_CHECK();
+    } else {
         ConvShape s{B, M, L, L, 1, 1, 0, C, 0, 0};
         EpiBiasAct::Params ep{ws + w.x0, packed + o.in_b, nullptr, 1.f, C, MG_ACT_RELU, 0, 0, nullptr};
         MG_TRY(conv_launch<EpiBiasAct>(s, x_t, nullptr, packed + o.in_w, ep, st));
     }
-    static const bool force_generic = std::getenv("MG_DENOISER_GENERIC") != nullptr;
-    const bool fused = !force_generic && C == RB_C && H == RB_C;
     if (split) {
         if (C != RB_C || H != RB_C) return MG_ERR_SHAPE;
         // conditioner -> frame-major bf16 hi/lo planes (once per call; every layer's tile stages from it)
@@ -405,6 +410,13 @@ extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, c
     }
     }
     // sum(skips)/sqrt(NL) -> skip_projection -> ReLU -> output_projection (model/modules.py:441-444)
+    if (fused && M <= 128) {
+        TailArgs ta{ws + w.skip, packed + o.skip_w, packed + o.skip_b, packed + o.out_w, packed + o.out_b,
+                    save ? ws + w.y : nullptr, out, 1.0f / sqrtf((float)NL), M, L, mg_cdiv(L, RB_NT)};
+        hipLaunchKernelGGL(denoiser_tail_kernel, dim3((unsigned)(ta.tiles_per_b * B)), dim3(512), 0, st, ta);
+        MG_LAUNCH_CHECK();
+        return MG_OK;
+    }
     {
         ConvShape s{B, C, L, L, 1, 1, 0, C, 0, 0};
         EpiBiasAct::Params ep{ws + w.y, packed + o.skip_b, nullptr, 1.0f / sqrtf((float)NL), C, MG_ACT_RELU, 0, 0, nullptr};

@@ -211,11 +211,35 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float *__restri
     float acc[BC];
 #pragma unroll
     for (int b = 0; b < BC; ++b) acc[b] = 0.f;
-    for (int i = lane; i < K; i += 64) {
-        const float wv = w[i];
+    if ((K & 255) == 0) {
+        // 16-byte loads, all of an iteration's loads independent (the scalar loop below is a chain of
+        // dependent L2 round trips: 17-35 us per launch for a few hundred kFLOP)
+        for (int i = lane * 4; i < K; i += 256) {
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + i);
+            f32x4 xv[BC];
 #pragma unroll
-        for (int b = 0; b < BC; ++b)
-            if (b0 + b < B) acc[b] = fmaf(wv, in[(size_t)(b0 + b) * K + i], acc[b]);
+            for (int b = 0; b < BC; ++b)
+                xv[b] = *reinterpret_cast<const f32x4 *>(in + (size_t)min(b0 + b, B - 1) * K + i);
+            // explicit fma chain: the same rounding for every batch slot (a free-form expression lets the
+            // SLP vectoriser pick packed mul+add for some slots and fma for others, which breaks bitwise
+            // batch independence)
+#pragma unroll
+            for (int b = 0; b < BC; ++b) {
+                float t = acc[b];
+                t = fmaf(wv[0], xv[b][0], t);
+                t = fmaf(wv[1], xv[b][1], t);
+                t = fmaf(wv[2], xv[b][2], t);
+                t = fmaf(wv[3], xv[b][3], t);
+                acc[b] = t;
+            }
+        }
+    } else {
+        for (int i = lane; i < K; i += 64) {
+            const float wv = w[i];
+#pragma unroll
+            for (int b = 0; b < BC; ++b)
+                if (b0 + b < B) acc[b] = fmaf(wv, in[(size_t)(b0 + b) * K + i], acc[b]);
+        }
     }
 #pragma unroll
     for (int b = 0; b < BC; ++b) {

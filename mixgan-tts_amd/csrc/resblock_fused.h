@@ -51,12 +51,12 @@ struct ResArgs {
 };
 
 // k-loop of one GEMM phase.  Rows of the B tile are channels; `bcol` is this lane's first column.
-template <int NMB, int NNB, int KW, int RS>
+template <int NMB, int NNB, int KW, int RS, int NCH = 8>
 __device__ __forceinline__ void rb_mfma_loop(f32x16 (&acc)[NMB][NNB], const f32x4 *ap0, int qstride_mb,
                                              const float *__restrict__ tile, int bcol)
 {
     constexpr int QC = KW * 4;       // k-groups per 32-channel chunk
-    constexpr int Q = 8 * QC;        // RB_C / 32 chunks
+    constexpr int Q = NCH * QC;      // NCH chunks of 32 input channels (8 = RB_C / 32)
     const f32x4 *ap[NMB];
 #pragma unroll
     for (int i = 0; i < NMB; ++i) ap[i] = ap0 + (size_t)i * qstride_mb;
@@ -64,7 +64,7 @@ __device__ __forceinline__ void rb_mfma_loop(f32x16 (&acc)[NMB][NNB], const f32x
 #pragma unroll
     for (int i = 0; i < NMB; ++i) a_cur[i] = ap[i][0];
     int q = 0;
-    for (int chunk = 0; chunk < 8; ++chunk) {
+    for (int chunk = 0; chunk < NCH; ++chunk) {
         const float *T = tile + chunk * 32 * RS + bcol;
 #pragma unroll
         for (int tap = 0; tap < KW; ++tap) {

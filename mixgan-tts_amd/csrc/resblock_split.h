@@ -374,23 +374,36 @@ __global__ void pack_split_kernel(const float *__restrict__ w, __bf16 *__restric
     }
 }
 
-// cond [B][256][L] fp32 -> condS [B][L][2][256] bf16 hi/lo (LDS-tiled transpose, 64 frames per block)
+// cond [B][256][L] fp32 -> condS [B][L][2][256] bf16 hi/lo (LDS-tiled transpose, 64 frames per block;
+// reads are 256-byte row segments, writes are 16-byte vectors of 8 channels)
 __global__ __launch_bounds__(256) void cond_split_kernel(const float *__restrict__ cond, __bf16 *__restrict__ out, int L)
 {
     __shared__ float tile[64][257];
     const int b = blockIdx.y, l0 = blockIdx.x * 64;
     const int nl = min(64, L - l0);
-    for (int idx = threadIdx.x; idx < 256 * 64; idx += 256) {
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) {
+        const int idx = threadIdx.x + k * 256;
         const int c = idx >> 6, l = idx & 63;
-        tile[l][c] = l < nl ? cond[((size_t)b * 256 + c) * L + l0 + l] : 0.f;
+        const float v = cond[((size_t)b * 256 + c) * L + min(l0 + l, L - 1)];
+        tile[l][c] = v;
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < nl * 256; idx += 256) {
-        const int l = idx >> 8, c = idx & 255;
-        const float v = tile[l][c];
-        const __bf16 h = (__bf16)v;
-        __bf16 *o = out + (((size_t)b * L + l0 + l) * 2) * 256 + c;
-        o[0] = h;
-        o[256] = (__bf16)(v - (float)h);
+    // 64 frames x 32 channel-octets = 2048 work items
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int idx = threadIdx.x + k * 256;
+        const int l = idx >> 5, c0 = (idx & 31) * 8;
+        if (l >= nl) continue;
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = tile[l][c0 + j];
+            hi[j] = (__bf16)v;
+            lo[j] = (__bf16)(v - (float)hi[j]);
+        }
+        __bf16 *o = out + (((size_t)b * L + l0 + l) * 2) * 256 + c0;
+        *reinterpret_cast<bf16x8 *>(o) = hi;
+        *reinterpret_cast<bf16x8 *>(o + 256) = lo;
     }
 }
