@@ -36,6 +36,10 @@ K3_FLOP_PER_FRAME = 2 * 512 * 768      # generic path's dominant kernel: Conv1d(
 # k=3 conv 256->512 + conditioner 1x1 256->256 + output 1x1 256->512 (algorithmic; halo MFMAs not counted)
 LAYER_FLOP_PER_FRAME = 2 * 512 * 768 + 2 * 256 * 256 + 2 * 512 * 256
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+# HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (profiles/r01_d_pmc_*.json):
+# (2 x FETCH_SIZE + WRITE_SIZE) x 1024 with the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md section HBM
+# (an upper bound here: only the 16-B/lane loads are under-counted); B=16, L=1000 only.
+TRAFFIC_BYTES = {"fp32": int((2 * 57156.66 + 32000.04) * 1024), "bf16x3": None}
 
 
 def main():
@@ -46,7 +50,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--frames", type=int, default=L_FRAMES)
-    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
+                    help="fp32: exact fp32 MFMA (headline). bf16x3: residual-layer GEMMs as 3-term bf16-split MFMA "
+                         "products with fp32 accumulate (opt-in, parity 2e-4); reported under 'alt'")
+    ap.add_argument("--no-alt", action="store_true", help="skip the second measurement in the other precision")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -78,77 +85,107 @@ def main():
             p.copy_(torch.randn(p.shape, generator=gen) * (fan ** -0.5 if p.dim() > 1 else 0.1))
     gd = gd.to(dev).eval()
     den = gd.denoise_fn
-    den.precision = args.precision
     rng = np.random.default_rng(1234 + rank)
     cond = torch.from_numpy(rng.standard_normal((B, 256, L)).astype(np.float32)).to(dev)
     x = torch.from_numpy(rng.standard_normal((B, MEL, L)).astype(np.float32)).to(dev)
     buf = gd._buf()
-    packed = den.packed_weights()
     T = gd.num_timesteps
     ts = [torch.full((B,), i, device=dev, dtype=torch.long) for i in range(T)]
     x0 = torch.empty_like(x)
     bufs = [torch.empty_like(x), torch.empty_like(x)]
     noise = torch.empty_like(x)
 
-    def step(i, xin, xout):
-        t = ts[(T - 1 - i) % T]
-        den.run(xin, t, cond, None, out=x0, packed=packed)
-        noise.normal_()
-        ops.posterior_sample(x0, xin, t, noise, None, buf, clip=True, out=xout)
-
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    cur = x
-    for i in range(args.warmup):
-        step(i, cur, bufs[i & 1])
-        cur = bufs[i & 1]
-    n_layers = len(den.residual_layers)
-    Lh = _lib.lib()
-    if not os.environ.get("MG_BENCH_NO_EVENTS"):
-        _lib.check(Lh.mg_profile_begin(args.steps * n_layers))
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, cur, bufs[i & 1])
-        cur = bufs[i & 1]
-    sync()
-    dt = time.perf_counter() - t0
-    ms = (ctypes.c_float * (args.steps * n_layers))()
-    n_ev = Lh.mg_profile_end(ms, args.steps * n_layers)
-    assert torch.isfinite(cur).all(), "non-finite output"
+    def measure(precision):
+        den.precision = precision
+        pk = den.packed_weights()
 
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        def step_(i, xin, xout):
+            t = ts[(T - 1 - i) % T]
+            den.run(xin, t, cond, None, out=x0, packed=pk)
+            noise.normal_()
+            ops.posterior_sample(x0, xin, t, noise, None, buf, clip=True, out=xout)
+
+        cur = x
+        for i in range(args.warmup):
+            step_(i, cur, bufs[i & 1])
+            cur = bufs[i & 1]
+        n_layers = len(den.residual_layers)
+        Lh = _lib.lib()
+        if not os.environ.get("MG_BENCH_NO_EVENTS"):
+            _lib.check(Lh.mg_profile_begin(args.steps * n_layers))
+        sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step_(i, cur, bufs[i & 1])
+            cur = bufs[i & 1]
+        sync()
+        dt = time.perf_counter() - t0
+        ms = (ctypes.c_float * (args.steps * n_layers))()
+        n_ev = Lh.mg_profile_end(ms, args.steps * n_layers)
+        assert torch.isfinite(cur).all(), "non-finite output"
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        k_ms = float(np.mean(np.frombuffer(ms, dtype=np.float32)[:n_ev])) if n_ev > 0 else float("nan")
+        return float(tmax.item()), k_ms, int(n_ev)
+
+    dt, k_ms, n_ev = measure(args.precision)
+    alt = None
+    if not args.no_alt:
+        other = "bf16x3" if args.precision == "fp32" else "fp32"
+        alt = (other,) + measure(other)
 
     if rank == 0:
-        k_ms = float(np.mean(np.frombuffer(ms, dtype=np.float32)[:n_ev])) if n_ev > 0 else float("nan")
-        generic = os.environ.get("MG_DENOISER_GENERIC") is not None
-        k_flop = (K3_FLOP_PER_FRAME if generic else LAYER_FLOP_PER_FRAME) * B * L
-        k_name = ("conv_mfma_kernel<K=3> 256->512 + GLU gate epilogue" if generic else
-                  "resblock_fused_kernel (one residual layer: cond 1x1 + k3 conv + gate + out 1x1 + res/skip)")
-        achieved = k_flop / (k_ms * 1e-3) / 1e12
+        BF16_PEAK = 2500.0  # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
+
+        def roof(precision, k_ms, n_ev, dt):
+            generic = os.environ.get("MG_DENOISER_GENERIC") is not None and precision == "fp32"
+            k_flop = (K3_FLOP_PER_FRAME if generic else LAYER_FLOP_PER_FRAME) * B * L
+            achieved = k_flop / (k_ms * 1e-3) / 1e12
+            whole = FLOP_PER_FRAME * B * L * args.steps / dt / 1e12
+            if precision == "fp32":
+                name = ("conv_mfma_kernel<K=3> 256->512 + GLU gate epilogue" if generic else
+                        "resblock_fused_kernel (one residual layer: cond 1x1 + k3 conv + gate + out 1x1 + res/skip), "
+                        "v_mfma_f32_32x32x2_f32")
+                peak = FP32_MFMA_PEAK_TFLOPS
+                extra = {}
+            else:
+                name = ("resblock_split_kernel (same layer; each product = 3 v_mfma_f32_32x32x16_bf16 on hi/lo "
+                        "bf16 pairs, fp32 accumulate)")
+                peak = BF16_PEAK
+                extra = {"executed_mfma_tflops": round(achieved * 3 * 2432 / 2304, 1),
+                         "vs_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 3)}
+            r = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                 "frac": round(achieved / peak, 4),
+                 "traffic": TRAFFIC_BYTES.get(precision) if (B, L) == (B_PER_GPU, L_FRAMES) else None, "kernel_ms": round(k_ms, 4),
+                 "launches_timed": n_ev, "whole_step_tflops": round(whole, 2),
+                 "whole_step_frac": round(whole / peak, 4)}
+            r.update(extra)
+            return r
+
         value = world * args.steps / dt
-        whole = FLOP_PER_FRAME * B * L * args.steps / dt / 1e12
+        dtype = {"fp32": "f32", "bf16x3": "bf16x3-split products, f32 accumulate and I/O"}
         line = {
             "metric": "denoiser steps/sec (80-mel, L=1000 frames, B=16 per GPU)",
             "value": round(value, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype[args.precision], "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: LJSpeech naive, p_sample step (Denoiser.forward + clamp + "
                                    "posterior sample), B=%d/GPU, L=%d, 80 mel, T=4 schedule" % (B, L),
                        "parallelism": "replicas x%d (batch-sharded, no collective)" % world},
-            "roofline": {"bound": "mfma", "kernel": k_name,
-                         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel_ms": round(k_ms, 4), "launches_timed": int(n_ev),
-                         "whole_step_tflops": round(whole, 2),
-                         "whole_step_frac": round(whole / FP32_MFMA_PEAK_TFLOPS, 4)},
+            "roofline": roof(args.precision, k_ms, n_ev, dt),
         }
+        if alt is not None:
+            a_prec, a_dt, a_kms, a_nev = alt
+            line["alt"] = {"dtype": dtype[a_prec], "value": round(world * args.steps / a_dt, 3), "unit": "steps/s",
+                           "ms_per_step": round(a_dt / args.steps * 1e3, 4), "parity": "2e-4 vs reference fixtures "
+                           "(tests/test_gpu_parity.py::test_denoiser_split_bf16_precision)" if a_prec == "bf16x3" else
+                           "2e-5 vs reference fixtures", "roofline": roof(a_prec, a_kms, a_nev, a_dt)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(gd, B, L)
             line["speedup_vs_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
