@@ -23,7 +23,6 @@
 #pragma once
 #include "common.h"
 
-#define MG_NT 128
 
 struct ConvArgs {
     const float *in;      // [B, Ci, Lin]
@@ -56,8 +55,8 @@ struct EpiBiasAct {
         long out_bs;       // batch stride of out (0 -> Co*Lout): lets the output be a channel slice
         const float *mask; // optional [B, Co, Lout] dense: result *= (mask > 0)   (ReLU backward)
     };
-    template <int WM>
-    static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][2], int b, int mrow0, int l0w,
+    template <int WM, int NNB>
+    static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][NNB], int b, int mrow0, int l0w,
                                                int lane, int Lout)
     {
         const int h = lane >> 5, c = lane & 31;
@@ -73,7 +72,7 @@ struct EpiBiasAct {
                 const float *arow = p.add ? p.add + dense : nullptr;
                 const float *mrow = p.mask ? p.mask + dense : nullptr;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NNB; ++j) {
                     const int l = l0w + j * 32 + c;
                     if (l < Lout) {
                         float v = acc[i][j][r] * p.alpha + bv;
@@ -95,10 +94,10 @@ struct EpiBiasAct {
 };
 
 // ---------------------------------------------------------------------------------------------
-template <int KW, int STRIDE, int CK, int WM, class Epi>
+template <int KW, int STRIDE, int CK, int WM, int NNB, class Epi>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, typename Epi::Params ep)
 {
-    constexpr int NT = MG_NT;
+    constexpr int NT = 64 * NNB;  // output frames per workgroup: 2 (N) waves x NNB 32-frame blocks
     constexpr int TW = NT * STRIDE + KW - 1;  // input frames per tile row (>= (NT-1)*STRIDE + KW)
     constexpr int TILE = CK * TW;
     constexpr int NLD = (TILE + 255) / 256;
@@ -126,11 +125,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, typename 
 #pragma unroll
     for (int i = 0; i < WM; ++i) ap[i] = reinterpret_cast<const f32x4 *>(a.wp) + ((size_t)(mb0 + i) * Q) * 64 + lane;
 
-    f32x16 acc[WM][2];
+    f32x16 acc[WM][NNB];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NNB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -171,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, typename 
     __syncthreads();
 
     int q = 0;
-    const int boff = (wn * 64 + c32) * STRIDE + h * TW;
+    const int boff = (wn * 32 * NNB + c32) * STRIDE + h * TW;
     for (int ch = 0; ch < nchunks; ++ch) {
         if (ch + 1 < nchunks) load_stage(ch + 1);
         const float *L = lds[ch & 1];
@@ -186,13 +185,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, typename 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int s = g * 4 + e;
-                    const float b0 = L[boff + (2 * s) * TW + tap];
-                    const float b1 = L[boff + (2 * s) * TW + tap + 32 * STRIDE];
+                    float bv[NNB];
 #pragma unroll
-                    for (int i = 0; i < WM; ++i) {
-                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][e], b0, acc[i][0], 0, 0, 0);
-                        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][e], b1, acc[i][1], 0, 0, 0);
-                    }
+                    for (int j = 0; j < NNB; ++j) bv[j] = L[boff + (2 * s) * TW + tap + 32 * j * STRIDE];
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < NNB; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][e], bv[j], acc[i][j], 0, 0, 0);
                 }
 #pragma unroll
                 for (int i = 0; i < WM; ++i) a_cur[i] = a_nxt[i];
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, typename 
         __syncthreads();
     }
 
-    Epi::template run<WM>(ep, acc, b, (mt * 2 + wm) * (32 * WM), l0 + wn * 64, lane, a.Lout);
+    Epi::template run<WM, NNB>(ep, acc, b, (mt * 2 + wm) * (32 * WM), l0 + wn * 32 * NNB, lane, a.Lout);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -214,7 +214,7 @@ struct ConvShape {
     int in_rs;   // 0 -> Lin
 };
 
-template <int KW, int STRIDE, int CK, int WM, class Epi>
+template <int KW, int STRIDE, int CK, int WM, int NNB, class Epi>
 static int conv_launch_t(const ConvShape &s, const float *in, const float *in_vec, const float *wp,
                          const typename Epi::Params &ep, hipStream_t st)
 {
@@ -230,26 +230,47 @@ static int conv_launch_t(const ConvShape &s, const float *in, const float *in_ve
     a.Lin = s.Lin;
     a.Lout = s.Lout;
     a.pad = s.pad;
-    a.ntiles_per_b = mg_cdiv(s.Lout, MG_NT);
+    a.ntiles_per_b = mg_cdiv(s.Lout, 64 * NNB);
     a.ntiles_total = a.ntiles_per_b * s.B;
     const int mtiles = mg_cdiv(s.Mrows, 64 * WM);
     dim3 grid((unsigned)(a.ntiles_total * mtiles));
-    hipLaunchKernelGGL((conv_mfma_kernel<KW, STRIDE, CK, WM, Epi>), grid, dim3(256), 0, st, a, ep);
+    hipLaunchKernelGGL((conv_mfma_kernel<KW, STRIDE, CK, WM, NNB, Epi>), grid, dim3(256), 0, st, a, ep);
     MG_LAUNCH_CHECK();
     return MG_OK;
 }
 
-// Dispatch on (K, stride); CK must match mg_conv_ck().  WM = 2 (MT = 128) when Mrows > 64.
+// Tile choice: the 128x128 workgroup tile unless that leaves most of the 256 CUs idle (short sequences,
+// few output channels: the JCU tail runs at L/4 frames with 128 or 1 output channels) -- then halve the
+// frame tile and/or the channel tile until there are at least 2 workgroups per CU or nothing is left to halve.
+template <class Epi>
+struct EpiNeedsWM2 { static constexpr bool value = false; };
+
+template <int KW, int STRIDE, int CK, class Epi>
+static int conv_launch_k(const ConvShape &s, const float *in, const float *in_vec, const float *wp,
+                         const typename Epi::Params &ep, hipStream_t st)
+{
+    const bool can_wm1 = !EpiNeedsWM2<Epi>::value;
+    // the packed form of <= 64 rows holds 2 blocks (WM = 1 only); wider ones are padded to 128 rows
+    const bool must_wm1 = s.Mrows <= 64;
+    auto wgs = [&](int wm, int nnb) { return (long)mg_cdiv(s.Mrows, 64 * wm) * mg_cdiv(s.Lout, 64 * nnb) * s.B; };
+    int wm = must_wm1 ? 1 : 2, nnb = 2;
+    if (wgs(wm, nnb) < 512) nnb = 1;
+    if (wgs(wm, nnb) < 512 && wm == 2 && can_wm1) wm = 1;
+    if (wm == 2)
+        return nnb == 2 ? conv_launch_t<KW, STRIDE, CK, 2, 2, Epi>(s, in, in_vec, wp, ep, st)
+                        : conv_launch_t<KW, STRIDE, CK, 2, 1, Epi>(s, in, in_vec, wp, ep, st);
+    return nnb == 2 ? conv_launch_t<KW, STRIDE, CK, 1, 2, Epi>(s, in, in_vec, wp, ep, st)
+                    : conv_launch_t<KW, STRIDE, CK, 1, 1, Epi>(s, in, in_vec, wp, ep, st);
+}
+
+// Dispatch on (K, stride); CK must match mg_conv_ck().
 template <class Epi>
 static int conv_launch(const ConvShape &s, const float *in, const float *in_vec, const float *wp,
                        const typename Epi::Params &ep, hipStream_t st)
 {
     if (s.B <= 0 || s.Lout <= 0 || s.Ci <= 0 || s.Mrows <= 0) return MG_ERR_SHAPE;
-    const bool big = s.Mrows > 64;
-#define MG_CONV_CASE(KW_, ST_, CK_)                                                              \
-    if (s.K == KW_ && s.stride == ST_)                                                           \
-        return big ? conv_launch_t<KW_, ST_, CK_, 2, Epi>(s, in, in_vec, wp, ep, st)            \
-                   : conv_launch_t<KW_, ST_, CK_, 1, Epi>(s, in, in_vec, wp, ep, st);
+#define MG_CONV_CASE(KW_, ST_, CK_) \
+    if (s.K == KW_ && s.stride == ST_) return conv_launch_k<KW_, ST_, CK_, Epi>(s, in, in_vec, wp, ep, st);
     MG_CONV_CASE(1, 1, 32)
     MG_CONV_CASE(3, 1, 32)
     MG_CONV_CASE(5, 1, 16)

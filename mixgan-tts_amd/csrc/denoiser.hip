@@ -23,8 +23,8 @@ struct EpiCond {
         const float *vec;   // [B, C]  (Wd s [+ Wp spk])
         int C;
     };
-    template <int WM>
-    static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][2], int b, int mrow0, int l0w,
+    template <int WM, int NNB>
+    static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][NNB], int b, int mrow0, int l0w,
                                                int lane, int Lout)
     {
         const int h = lane >> 5, c = lane & 31;
@@ -37,7 +37,7 @@ struct EpiCond {
                 const float add = p.bias[row] + p.vec[(size_t)b * p.C + row];
                 const size_t ro = ((size_t)b * p.C + row) * Lout;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NNB; ++j) {
                     const int l = l0w + j * 32 + c;
                     if (l < Lout) p.out[ro + l] = acc[i][j][r] + add + p.x[ro + l];
                 }
@@ -54,8 +54,8 @@ struct EpiGate {
         float *tnh;
         int C;
     };
-    template <int WM>
-    static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][2], int b, int mrow0, int l0w,
+    template <int WM, int NNB>
+    static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][NNB], int b, int mrow0, int l0w,
                                                int lane, int Lout)
     {
         // needs the gate/filter 32-row block pair in one wave: only the WM == 2 tiling is launched
@@ -69,7 +69,7 @@ struct EpiGate {
             const float bg = p.bias[ch], bf = p.bias[p.C + ch];
             const size_t ro = ((size_t)b * p.C + ch) * Lout;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NNB; ++j) {
                 const int l = l0w + j * 32 + c;
                 if (l < Lout) {
                     const float s = mg_sigmoid(acc[0][j][r] + bg);
@@ -85,6 +85,9 @@ struct EpiGate {
     }
 };
 
+template <>
+struct EpiNeedsWM2<EpiGate> { static constexpr bool value = true; };
+
 struct EpiResSkip {
     struct Params {
         float *x;           // [B, C, L] in/out
@@ -94,8 +97,8 @@ struct EpiResSkip {
         int C;
         int first;          // layer 0: skip = ..., else skip += ...
     };
-    template <int WM>
-    static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][2], int b, int mrow0, int l0w,
+    template <int WM, int NNB>
+    static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][NNB], int b, int mrow0, int l0w,
                                                int lane, int Lout)
     {
         const int h = lane >> 5, c = lane & 31;
@@ -111,14 +114,14 @@ struct EpiResSkip {
                     const float dv = p.dvec[(size_t)b * p.C + row];
                     const size_t ro = ((size_t)b * p.C + row) * Lout;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < NNB; ++j) {
                         const int l = l0w + j * 32 + c;
                         if (l < Lout) p.x[ro + l] = (acc[i][j][r] + bv + (p.x[ro + l] + dv)) * rs2;
                     }
                 } else {
                     const size_t ro = ((size_t)b * p.C + (row - p.C)) * Lout;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < NNB; ++j) {
                         const int l = l0w + j * 32 + c;
                         if (l < Lout) {
                             const float v = acc[i][j][r] + bv;

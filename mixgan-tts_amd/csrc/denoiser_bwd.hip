@@ -19,8 +19,8 @@ struct EpiGateBwd {
         const float *tnh;  // [B, C, L] tanh(filter)
         int C;
     };
-    template <int WM>
-    static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][2], int b, int mrow0, int l0w,
+    template <int WM, int NNB>
+    static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][NNB], int b, int mrow0, int l0w,
                                                int lane, int Lout)
     {
         const int h = lane >> 5, c = lane & 31;
@@ -33,7 +33,7 @@ struct EpiGateBwd {
                 const size_t so = ((size_t)b * p.C + ch) * Lout;
                 const size_t zo = ((size_t)b * 2 * p.C + ch) * Lout;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NNB; ++j) {
                     const int l = l0w + j * 32 + c;
                     if (l < Lout) {
                         const float dg = acc[i][j][r];
@@ -54,8 +54,8 @@ struct EpiDhBwd {
         float *dout;     // [B, 2C, L]; rows < C hold dx_{l+1}/sqrt2 on entry, dx_l/sqrt2 on exit
         int C;
     };
-    template <int WM>
-    static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][2], int b, int mrow0, int l0w,
+    template <int WM, int NNB>
+    static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][NNB], int b, int mrow0, int l0w,
                                                int lane, int Lout)
     {
         const int h = lane >> 5, c = lane & 31;
@@ -69,7 +69,7 @@ struct EpiDhBwd {
                 float *dh = p.dh + (size_t)b * p.dh_bs + (size_t)ch * Lout;
                 float *dx = p.dout + ((size_t)b * 2 * p.C + ch) * Lout;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NNB; ++j) {
                     const int l = l0w + j * 32 + c;
                     if (l < Lout) {
                         const float v = acc[i][j][r];
@@ -237,8 +237,12 @@ extern "C" int mg_denoiser_bwd(const mg_denoiser_dims *d, const float *packed, c
     };
     auto linear_t = [&](const float *W, long w_zs, const float *a, long a_zs, long a_bs, float *out, int Z, int N,
                         int K) {
-        hipLaunchKernelGGL(small_linear_t_kernel, dim3(mg_cdiv(B * K, 256)), dim3(256), 0, st, W, w_zs, a, a_zs, a_bs, out,
-                           Z, B, N, K);
+        if (Z > 1) {
+            const hipError_t em = hipMemsetAsync(out, 0, (size_t)B * K * sizeof(float), st);
+            if (em != hipSuccess) return (int)em;
+        }
+        hipLaunchKernelGGL(small_linear_t_kernel, dim3(mg_cdiv(K, 64), B, Z), dim3(256), 0, st, W, w_zs, a, a_zs, a_bs,
+                           out, Z, B, N, K);
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? MG_OK : (int)e;
     };

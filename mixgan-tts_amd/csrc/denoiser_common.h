@@ -283,20 +283,31 @@ static __global__ void small_outer_kernel(const float *__restrict__ a, long a_zs
     }
 }
 
-// out[b][j] = sum_z sum_i W[z*w_zs + i*K + j] * a[z*a_zs + b*a_bs + i]   (transposed linears, summed over layers)
-static __global__ void small_linear_t_kernel(const float *__restrict__ W, long w_zs, const float *__restrict__ a, long a_zs,
-                                      long a_bs, float *__restrict__ out, int Z, int B, int N, int K)
+// out[b][j] (+)= sum_z sum_i W[z*w_zs + i*K + j] * a[z*a_zs + b*a_bs + i]   (transposed linears, summed over layers)
+// grid (K/64, B, Z): lanes run along j (coalesced rows of W), the 4 waves split i, one fp32 atomic per
+// (z, b, j) when Z > 1 (out must be zeroed by the caller then).
+static __global__ __launch_bounds__(256) void small_linear_t_kernel(const float *__restrict__ W, long w_zs,
+                                                                    const float *__restrict__ a, long a_zs, long a_bs,
+                                                                    float *__restrict__ out, int Z, int B, int N, int K)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * K) return;
-    const int b = idx / K, j = idx - b * K;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + lane;
+    const int b = blockIdx.y, z = blockIdx.z;
+    const float *w = W + (size_t)z * w_zs + min(j, K - 1);
+    const float *av = a + (size_t)z * a_zs + (size_t)b * a_bs;
+    const int per = (N + 3) / 4;
+    const int i0 = wave * per, i1 = min(N, i0 + per);
     float s = 0.f;
-    for (int z = 0; z < Z; ++z) {
-        const float *w = W + (size_t)z * w_zs + j;
-        const float *av = a + (size_t)z * a_zs + (size_t)b * a_bs;
-        for (int i = 0; i < N; ++i) s = fmaf(w[(size_t)i * K], av[i], s);
+#pragma unroll 8
+    for (int i = i0; i < i1; ++i) s = fmaf(w[(size_t)i * K], av[i], s);
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && j < K) {
+        const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        if (Z > 1) atomicAdd(out + (size_t)b * K + j, t);
+        else out[(size_t)b * K + j] = t;
     }
-    out[idx] = s;
 }
 
 // da = dm * mish'(x),  mish'(x) = tanh(sp) + x (1 - tanh(sp)^2) sigmoid(x),  sp = softplus(x)

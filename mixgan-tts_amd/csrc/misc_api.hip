@@ -80,7 +80,7 @@ static int outer(const float *a, long a_zs, long a_bs, const float *c, float *ou
 
 static int linear_t(const float *W, const float *a, float *out, int B, int N, int K, hipStream_t st)
 {
-    hipLaunchKernelGGL(small_linear_t_kernel, dim3(mg_cdiv(B * K, 256)), dim3(256), 0, st, W, 0, a, 0, (long)N, out, 1, B,
+    hipLaunchKernelGGL(small_linear_t_kernel, dim3(mg_cdiv(K, 64), B, 1), dim3(256), 0, st, W, 0, a, 0, (long)N, out, 1, B,
                        N, K);
     MG_LAUNCH_CHECK();
     return MG_OK;
