@@ -73,33 +73,46 @@ __global__ __launch_bounds__(256) void mel_l1_kernel(const float *__restrict__ p
                                                      float *__restrict__ out, const float *__restrict__ g,
                                                      const float *__restrict__ den, float *__restrict__ dpred)
 {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const bool padded = pad && pad[row];
-    const float *p = pred + (size_t)row * M, *t = targ + (size_t)row * M;
-    float tabs = 0.f, l1 = 0.f;
-    for (int m = lane; m < M; m += 64) {
-        const float tv = padded ? 0.f : t[m], pv = padded ? 0.f : p[m];
-        tabs += fabsf(tv);
-        l1 += fabsf(pv - tv);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        tabs += __shfl_xor(tabs, o, 64);
-        l1 += __shfl_xor(l1, o, 64);
-    }
-    const float w = tabs != 0.f ? 1.f : 0.f;
-    if (!dpred) {
-        if (lane == 0 && w != 0.f) {
-            atomicAdd(out, l1);
-            atomicAdd(out + 1, (float)M);
-        }
-    } else {
-        const float k = (padded || w == 0.f) ? 0.f : g[0] / den[0];
+    // one wave per row, grid-stride over rows; forward sums are combined per workgroup so that only
+    // gridDim.x atomics land on the two result words (same-address atomics serialise)
+    __shared__ float red[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc_l1 = 0.f, acc_n = 0.f;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const bool padded = pad && pad[row];
+        const float *p = pred + (size_t)row * M, *t = targ + (size_t)row * M;
+        float tabs = 0.f, l1 = 0.f;
         for (int m = lane; m < M; m += 64) {
-            const float d = p[m] - t[m];
-            dpred[(size_t)row * M + m] = d > 0.f ? k : (d < 0.f ? -k : 0.f);
+            const float tv = padded ? 0.f : t[m], pv = padded ? 0.f : p[m];
+            tabs += fabsf(tv);
+            l1 += fabsf(pv - tv);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            tabs += __shfl_xor(tabs, o, 64);
+            l1 += __shfl_xor(l1, o, 64);
+        }
+        const float w = tabs != 0.f ? 1.f : 0.f;
+        if (!dpred) {
+            acc_l1 += w * l1;
+            acc_n += w * (float)M;
+        } else {
+            const float k = (padded || w == 0.f) ? 0.f : g[0] / den[0];
+            for (int m = lane; m < M; m += 64) {
+                const float d = p[m] - t[m];
+                dpred[(size_t)row * M + m] = d > 0.f ? k : (d < 0.f ? -k : 0.f);
+            }
+        }
+    }
+    if (!dpred) {
+        if (lane == 0) {
+            red[0][wave] = acc_l1;
+            red[1][wave] = acc_n;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(out, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+            atomicAdd(out + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
         }
     }
 }
@@ -112,8 +125,8 @@ extern "C" int mg_mel_l1_fwd(const float *pred, const float *targ, const uint8_t
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(out2, 0, 2 * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(mel_l1_kernel, dim3(mg_cdiv(rows, 4)), dim3(256), 0, st, pred, targ, pad, rows, M, out2, nullptr,
-                       nullptr, nullptr);
+    hipLaunchKernelGGL(mel_l1_kernel, dim3(min(mg_cdiv(rows, 4), 512)), dim3(256), 0, st, pred, targ, pad, rows, M, out2,
+                       nullptr, nullptr, nullptr);
     MG_LAUNCH_CHECK();
     return MG_OK;
 }
@@ -123,8 +136,8 @@ extern "C" int mg_mel_l1_bwd(const float *pred, const float *targ, const uint8_t
 {
     if (!pred || !targ || !g || !den || !dpred) return MG_ERR_ARG;
     if (rows <= 0 || M <= 0) return MG_ERR_SHAPE;
-    hipLaunchKernelGGL(mel_l1_kernel, dim3(mg_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, pred, targ, pad, rows, M,
-                       nullptr, g, den, dpred);
+    hipLaunchKernelGGL(mel_l1_kernel, dim3(min(mg_cdiv(rows, 4), 2048)), dim3(256), 0, (hipStream_t)stream, pred, targ, pad,
+                       rows, M, nullptr, g, den, dpred);
     MG_LAUNCH_CHECK();
     return MG_OK;
 }

@@ -170,7 +170,9 @@ static int wgrad_launch(const WgradShape &s, const float *dy, const float *x, co
     a.nchunks = a.chunks_per_b * s.B;
     a.ci_tiles = mg_cdiv(s.Ci, 128);
     const int tiles = mg_cdiv(s.Co, 128) * a.ci_tiles * s.K;
-    int nsplit = mg_cdiv(512, tiles);  // two workgroups per CU in flight
+    // two workgroups per CU are resident (66.5 KB LDS each): keep the grid within ONE round of 512
+    // workgroups -- 560 workgroups take two rounds, i.e. twice the time of 504
+    int nsplit = 512 / tiles;
     if (nsplit > a.nchunks) nsplit = a.nchunks;
     if (nsplit < 1) nsplit = 1;
     a.nsplit = nsplit;

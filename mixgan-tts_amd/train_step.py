@@ -44,7 +44,11 @@ class HotPathTrainer:
         """One D phase + one G phase on a batch.  mel [B,L,M]; cond [B,L,H]; mel_pad_mask True = pad."""
         G, D = self.G, self.D
         # ---------------- D phase (train.py:133-146)
-        x0, x_ts, x_prevs, x_prev_preds, t = G(mel, cond, spk, mel_pad_mask, coarse_mel)
+        # train.py:133 builds (and discards) the generator's autograd graph here; every output is detached
+        # before use (train.py:135-137), so running it under no_grad gives identical results and skips
+        # the activation saves of the grad-enabled forward.
+        with torch.no_grad():
+            x0, x_ts, x_prevs, x_prev_preds, t = G(mel, cond, spk, mel_pad_mask, coarse_mel)
         x_ts_d, x_prevs_d, x_pp_d = x_ts.detach(), x_prevs.detach(), x_prev_preds.detach()
         spk_d = spk.detach() if spk is not None else None
         f_c, f_u = D(x_ts_d, x_pp_d, spk_d, t)
