@@ -51,53 +51,80 @@ struct ResArgs {
 };
 
 // k-loop of one GEMM phase.  Rows of the B tile are channels; `bcol` is this lane's first column.
+// Software pipeline in registers with static indices (k-groups of 8 channels, unrolled by 4):
+// the weight float4s run 2 k-groups ahead (ring of 4), the B fragments one k-group ahead (double
+// buffer); each k-group's prefetches are issued at its top and pinned there with sched_barrier (left
+// alone, the scheduler sinks loads next to their use and the MFMAs wait on the round trip).
 template <int NMB, int NNB, int KW, int RS, int NCH = 8>
 __device__ __forceinline__ void rb_mfma_loop(f32x16 (&acc)[NMB][NNB], const f32x4 *ap0, int qstride_mb,
                                              const float *__restrict__ tile, int bcol)
 {
-    constexpr int QC = KW * 4;       // k-groups per 32-channel chunk
-    constexpr int Q = NCH * QC;      // NCH chunks of 32 input channels (8 = RB_C / 32)
+    constexpr int TC = NCH * KW;     // (chunk, tap) pairs; 4 k-groups each
+    constexpr int Q = TC * 4;
+    constexpr int DIST = 2;
     const f32x4 *ap[NMB];
 #pragma unroll
     for (int i = 0; i < NMB; ++i) ap[i] = ap0 + (size_t)i * qstride_mb;
-    f32x4 a_cur[NMB], a_nxt[NMB];
+    f32x4 ring[4][NMB];
+    float bb[2][4][NNB];
+    const float *T0 = tile + bcol;
 #pragma unroll
-    for (int i = 0; i < NMB; ++i) a_cur[i] = ap[i][0];
-    int q = 0;
-    for (int chunk = 0; chunk < NCH; ++chunk) {
-        const float *T = tile + chunk * 32 * RS + bcol;
+    for (int s = 0; s < DIST; ++s)
 #pragma unroll
-        for (int tap = 0; tap < KW; ++tap) {
+        for (int i = 0; i < NMB; ++i) ring[s][i] = ap[i][(size_t)s * 64];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                ++q;
-                const int qn = q < Q ? q : Q - 1;
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < NNB; ++j) bb[0][e][j] = T0[(2 * e) * RS + 32 * j];
+    for (int tc = 0; tc < TC; ++tc) {
+        const int tcn = tc + 1 < TC ? tc + 1 : TC - 1;
+        const int off_cur = (tc / KW) * (32 * RS) + (tc % KW);
+        const int off_nxt = (tcn / KW) * (32 * RS) + (tcn % KW);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = tc * 4 + u;
+            const int qa = q + DIST < Q ? q + DIST : Q - 1;
 #ifdef RB_ABLATE_A  // diagnostic builds only (tools/ubench): drop the weight stream
 #pragma unroll
-                for (int i = 0; i < NMB; ++i) a_nxt[i] = a_cur[i];
-                (void)qn;
+            for (int i = 0; i < NMB; ++i) ring[(u + DIST) & 3][i] = ring[u][i];
+            (void)qa;
 #else
 #pragma unroll
-                for (int i = 0; i < NMB; ++i) a_nxt[i] = ap[i][(size_t)qn * 64];
+            for (int i = 0; i < NMB; ++i) ring[(u + DIST) & 3][i] = ap[i][(size_t)qa * 64];
 #endif
+            {
+                // next k-group: g = u+1 in the same (chunk, tap), or g = 0 of the next one
+                const float *Tn = T0 + (u < 3 ? off_cur + ((u + 1) * 8) * RS : off_nxt);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float bv[NNB];
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
+                    for (int j = 0; j < NNB; ++j) {
 #ifdef RB_ABLATE_B  // diagnostic builds only: drop the LDS operand reads
-                    for (int j = 0; j < NNB; ++j) bv[j] = a_cur[0][(e + j) & 3];
+                        bb[(u + 1) & 1][e][j] = ring[u][0][(e + j) & 3];
+                        (void)Tn;
 #else
-                    for (int j = 0; j < NNB; ++j) bv[j] = T[(g * 8 + 2 * e) * RS + 32 * j + tap];
+                        bb[(u + 1) & 1][e][j] = Tn[(2 * e) * RS + 32 * j];
 #endif
-#pragma unroll
-                    for (int i = 0; i < NMB; ++i)
-#pragma unroll
-                        for (int j = 0; j < NNB; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][e], bv[j], acc[i][j], 0, 0, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < NMB; ++i) a_cur[i] = a_nxt[i];
+                    }
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < NMB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NNB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[u][i][e], bb[u & 1][e][j], acc[i][j], 0, 0, 0);
+#ifdef RB_INTERLEAVE  // measured slower for the fp32 MFMA (170.8 vs 163.6 us); kept for the record
+            // issue order inside the k-group: [1 global load][DS reads][MFMAs] repeated
+            constexpr int NM = 4 * NMB * NNB, ND = 4 * NNB;
+#pragma unroll
+            for (int g = 0; g < NMB; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              // VMEM read
+                __builtin_amdgcn_sched_group_barrier(0x100, ND / NMB, 0);       // DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, NM / NMB, 0);       // MFMA
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
