@@ -63,11 +63,18 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # MG_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box only): every rank on cuda:0 over gloo
+        share = os.environ.get("MG_BENCH_SHARE_GPU") == "1"
+        dev_index = 0 if share else local_rank
+        torch.cuda.set_device(dev_index)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
     else:
+        dev_index = 0
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
 
     import mixgan_tts_amd as mg
     from mixgan_tts_amd import ops, _lib
