@@ -28,6 +28,10 @@ struct WgradArgs {
     int chunks_per_b, nchunks, nsplit, ci_tiles;
 };
 
+// VEC: 16-byte staging loads (needs stride 1, Ldy % 4 == 0, Lx % 4 == 0, 16-byte aligned bases, no xvec):
+// the dY tile is 16 float4 per row; the X tile is read as the aligned 17-float4 window that contains
+// the tap-shifted 64 frames and scattered into the LDS tile with the shift applied.
+template <bool VEC>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a)
 {
     __shared__ float lds[2][WG_TILE];  // [A|B], single-buffered (66.5 KB -> two workgroups per CU)
@@ -50,47 +54,99 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float sa[32], sb[32];
+    constexpr int NSA = VEC ? 8 : 32, NSB = VEC ? 9 : 32;
+    f32x4 va[VEC ? 8 : 1], vb[VEC ? 9 : 1];
+    float sa[VEC ? 1 : 8], sb[VEC ? 1 : 8];  // scalar path stages in 4 batches of 8 (no prefetch, no spill)
+    const int shift = tap - a.pad;
+    const int shift4 = shift & ~3, rsh = shift & 3;  // aligned window start and residual (VEC)
+    (void)NSA; (void)NSB; (void)shift4; (void)rsh;
     auto load_stage = [&](int chunk) {
         const int b = chunk / a.chunks_per_b;
         const int f0 = (chunk - b * a.chunks_per_b) * WG_FT;
         const float *dyb = a.dy + (size_t)b * a.dy_bs;
         const float *xb = a.x + (size_t)b * a.x_bs;
+        if (VEC) {
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            const int idx = tid + k * 256;  // 128 rows x 64 frames
-            const int row = idx >> 6, c = idx & 63;
-            const int f = f0 + c;
-            {
-                const int co = co0 + row;
+            for (int k = 0; k < 8; ++k) {
+                const int idx = tid + k * 256;  // 128 rows x 16 float4
+                const int row = idx >> 4, c4 = idx & 15;
+                const int co = co0 + row, f = f0 + 4 * c4;
                 const bool ok = co < a.Co && f < a.Ldy;
-                const float v = dyb[(size_t)min(co, a.Co - 1) * a.Ldy + min(f, a.Ldy - 1)];
-                sa[k] = ok ? v : 0.f;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(dyb + (size_t)min(co, a.Co - 1) * a.Ldy + min(f, a.Ldy - 4));
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                va[k] = ok ? v : z;
             }
-            {
-                const int ci = ci0 + row;
-                const int xf = f * a.stride + tap - a.pad;
-                const bool ok = ci < a.Ci && f < a.Ldy && xf >= 0 && xf < a.Lx;
-                const int cic = min(ci, a.Ci - 1);
-                float v = xb[(size_t)cic * a.Lx + min(max(xf, 0), a.Lx - 1)];
-                if (a.xvec) v += a.xvec[(size_t)b * a.Ci + cic];
-                sb[k] = ok ? v : 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int idx = tid + k * 256;  // 128 rows x 17 float4 = 2176
+                const int row = idx / 17, c4 = idx - row * 17;
+                const int ci = ci0 + row, xf = f0 + shift4 + 4 * c4;
+                const bool ok = idx < 128 * 17 && ci < a.Ci && xf >= 0 && xf < a.Lx;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(xb + (size_t)min(ci, a.Ci - 1) * a.Lx + min(max(xf, 0), a.Lx - 4));
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                vb[k] = ok ? v : z;
+            }
+        } else {
+#pragma unroll 1
+            for (int kb = 0; kb < 32; kb += 8) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int idx = tid + (kb + k) * 256;  // 128 rows x 64 frames
+                    const int row = idx >> 6, c = idx & 63;
+                    const int f = f0 + c;
+                    {
+                        const int co = co0 + row;
+                        const bool ok = co < a.Co && f < a.Ldy;
+                        const float v = dyb[(size_t)min(co, a.Co - 1) * a.Ldy + min(f, a.Ldy - 1)];
+                        sa[k] = ok ? v : 0.f;
+                    }
+                    {
+                        const int ci = ci0 + row;
+                        const int xf = f * a.stride + shift;
+                        const bool ok = ci < a.Ci && f < a.Ldy && xf >= 0 && xf < a.Lx;
+                        const int cic = min(ci, a.Ci - 1);
+                        float v = xb[(size_t)cic * a.Lx + min(max(xf, 0), a.Lx - 1)];
+                        if (a.xvec) v += a.xvec[(size_t)b * a.Ci + cic];
+                        sb[k] = ok ? v : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int idx = tid + (kb + k) * 256;
+                    const int row = idx >> 6, c = idx & 63;
+                    lds[0][row * WG_RS + c] = sa[k];
+                    lds[1][row * WG_RS + c] = sb[k];
+                }
             }
         }
     };
     auto store_stage = [&]() {
+        if (VEC) {
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            const int idx = tid + k * 256;
-            const int row = idx >> 6, c = idx & 63;
-            lds[0][row * WG_RS + c] = sa[k];
-            lds[1][row * WG_RS + c] = sb[k];
+            for (int k = 0; k < 8; ++k) {
+                const int idx = tid + k * 256;
+                const int row = idx >> 4, c4 = idx & 15;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lds[0][row * WG_RS + 4 * c4 + j] = va[k][j];
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int idx = tid + k * 256;
+                const int row = idx / 17, c4 = idx - row * 17;
+                if (idx < 128 * 17) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = 4 * c4 + j - rsh;  // tile column of window element (4 c4 + j)
+                        if (c >= 0 && c < WG_FT) lds[1][row * WG_RS + c] = vb[k][j];
+                    }
+                }
+            }
         }
     };
 
     int chunk = split;
     if (chunk < a.nchunks) {
-        load_stage(chunk);
+        load_stage(chunk);  // the scalar path writes LDS itself
         store_stage();
     }
     __syncthreads();
@@ -98,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a)
     const float *Bt = lds[1] + (wn * 64 + c32) * WG_RS + hh;
     for (; chunk < a.nchunks; chunk += a.nsplit) {
         const bool more = chunk + a.nsplit < a.nchunks;
-        if (more) load_stage(chunk + a.nsplit);  // global loads fly behind the MFMAs below
+        if (VEC && more) load_stage(chunk + a.nsplit);  // global loads fly behind the MFMAs below
 #pragma unroll 8
         for (int s = 0; s < WG_FT / 2; ++s) {
             const float a0 = A[2 * s], a1 = A[32 * WG_RS + 2 * s];
@@ -109,7 +165,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a)
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
         __syncthreads();  // every wave is done reading the tiles
-        if (more) store_stage();
+        if (more) {
+            if (VEC) store_stage();
+            else load_stage(chunk + a.nsplit);
+        }
         __syncthreads();
     }
 
@@ -180,7 +239,10 @@ static int wgrad_launch(const WgradShape &s, const float *dy, const float *x, co
     hipError_t e = hipMemsetAsync(scratch, 0, n * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
     dim3 grid(nsplit, mg_cdiv(s.Co, 128) * a.ci_tiles, s.K);
-    hipLaunchKernelGGL(wgrad_mfma_kernel, grid, dim3(256), 0, st, a);
+    const bool vec = s.stride == 1 && !xvec && (s.Ldy % 4 == 0) && (s.Lx % 4 == 0) && (a.dy_bs % 4 == 0) &&
+                     (a.x_bs % 4 == 0) && ((((uintptr_t)dy | (uintptr_t)x) & 15) == 0) && s.Ldy >= 4 && s.Lx >= 4;
+    if (vec) hipLaunchKernelGGL(wgrad_mfma_kernel<true>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wgrad_mfma_kernel<false>, grid, dim3(256), 0, st, a);
     MG_LAUNCH_CHECK();
     const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, st, scratch, dw, s.Co, s.Ci, s.K, alpha,
