@@ -133,3 +133,19 @@ def test_mixgantts_forward_inference_vs_oracle(mg, manifest, tmp_path, model):
         assert_close(coarse.cpu(), coarse_ref, 5e-5, "coarse mel")
         assert_close(out[15].cpu(), coarse_ref, 5e-5, "postnet_outputs slot")
     assert_close(out[0].cpu(), ref, 1e-4, "final mel")
+
+
+def test_attention_long_form_L4000(mg, manifest):
+    """cfg5 length (L=4000): the reference materialises a [2B, L, L] score tensor (SURVEY.md section 5);
+    the streaming kernel must agree with it without ever holding more than a 64-key tile."""
+    W, _ = seeded(manifest, "fftblock", 123)
+    gen = torch.Generator().manual_seed(4000)
+    B, L = 1, 4000
+    x = torch.randn(B, L, 256, generator=gen)
+    pad = torch.arange(L)[None, :] >= torch.tensor([3777])[:, None]
+    ref = R.mha_forward(W, "slf_attn.", x, pad)
+    blk = mg.FFTBlock(256, 2, 128, 128, 1024, 9)
+    load_seeded(blk, manifest, "fftblock", 123)
+    blk = blk.cuda().eval()
+    y = blk.slf_attn.forward_cm(mg.ops.transpose_bml(x.cuda(), False), pad.to(torch.uint8).cuda())
+    assert_close(mg.ops.transpose_bml(y, True).cpu(), ref, 3e-5, "MHA L=4000")
