@@ -246,6 +246,8 @@ int mg_layernorm_cm_fwd(const float *a, const float *res, const float *gamma, co
  * gated convolution of a residual layer) with HIP events recorded on the launch stream.
  * mg_profile_end waits for them and returns the number of brackets written to ms_out. */
 int mg_profile_begin(int max_brackets);
+/* As above, bracketing only every `every`-th launch (keeps the events' own cost out of the timing). */
+int mg_profile_begin_sampled(int max_brackets, int every);
 int mg_profile_end(float *ms_out, int max_out);
 
 #ifdef __cplusplus

@@ -15,7 +15,7 @@ EXPORTS = (
     "mg_diffuse_fwd", "mg_posterior_sample_fwd", "mg_posterior_sample_bwd", "mg_spec_affine", "mg_transpose_bml",
     "mg_denoiser_packed_floats", "mg_denoiser_pack", "mg_denoiser_workspace_floats", "mg_denoiser_fwd",
     "mg_denoiser_bwd_workspace_floats", "mg_denoiser_bwd",
-    "mg_profile_begin", "mg_profile_end", "mg_transpose_bml_strided", "mg_act_bwd", "mg_upsample_zero",
+    "mg_profile_begin", "mg_profile_begin_sampled", "mg_profile_end", "mg_transpose_bml_strided", "mg_act_bwd", "mg_upsample_zero",
     "mg_step_mlp_fwd", "mg_step_mlp_bwd", "mg_linear_small_fwd", "mg_linear_small_bwd",
     "mg_loss_sum", "mg_loss_grad", "mg_mel_l1_fwd", "mg_mel_l1_bwd", "mg_attention_fwd", "mg_layernorm_cm_fwd",
 )
@@ -97,6 +97,7 @@ def _declare(L):
         "mg_attention_fwd": (i, [vp, vp, vp, i, i, i, i, f, vp]),
         "mg_layernorm_cm_fwd": (i, [vp, vp, vp, vp, vp, vp, i, i, i, f, vp]),
         "mg_profile_begin": (i, [i]),
+        "mg_profile_begin_sampled": (i, [i, i]),
         "mg_profile_end": (i, [vp, i]),
     }
     for name, (res, args) in sig.items():

@@ -113,7 +113,7 @@ class GaussianDiffusion(nn.Module):
         return ops.posterior_sample(x0, x, t.contiguous(), noise, None, self._buf(), clip=clip_denoised)[:, None]
 
     @torch.no_grad()
-    def sampling(self, noise=None, keep_trace=True, use_graph=False):
+    def sampling(self, noise=None, keep_trace=True, use_graph=False, _final_keep=None):
         """Reverse process from the stashed cond/spk (model/diffusion.py:155-165).
         Returns the list of denormalised mels [B,L,M] (T+1 entries, or only the last).
         use_graph=True replays the whole T-step loop as one captured hipGraph (static shapes, t read
@@ -125,7 +125,7 @@ class GaussianDiffusion(nn.Module):
         if use_graph and self.noise_fn is None:
             x = self._bml(torch.randn((B, 1, M, L), device=dev) if noise is None else noise)
             x = self._sampling_graph(x, cond, self.spk_emb)
-            return [ops.transpose_bml(x, True, 2, self.spec_min, self.spec_max)]
+            return [ops.transpose_bml(x, True, 2, self.spec_min, self.spec_max, _final_keep)]
         buf = self._buf()
         den = self.denoise_fn
         packed = den.packed_weights()
@@ -140,7 +140,8 @@ class GaussianDiffusion(nn.Module):
             if keep_trace:
                 xs.append(x)
         outs = xs if keep_trace else [x]
-        return [ops.transpose_bml(a, True, 2, self.spec_min, self.spec_max) for a in outs]
+        res = [ops.transpose_bml(a, True, 2, self.spec_min, self.spec_max) for a in outs[:-1]]
+        return res + [ops.transpose_bml(outs[-1], True, 2, self.spec_min, self.spec_max, _final_keep)]
 
     def _sampling_graph(self, x_start, cond, spk):
         """The T-step p_sample loop as one hipGraph: captured once per (B, L, T, device) on a side
@@ -229,7 +230,8 @@ class GaussianDiffusion(nn.Module):
             else:
                 t = torch.full((B,), self.num_timesteps - 1, device=dev, dtype=torch.long)
                 noise = self.diffuse_fn(coarse_mel, t, keep=keep)
-            x_0_pred = self.sampling(noise=noise, keep_trace=False)[-1] * (~mel_mask).unsqueeze(-1)
+            # final mel: denorm + [B,M,L]->[B,L,M] + mask multiply (:164,:200) fused in one transpose kernel
+            x_0_pred = self.sampling(noise=noise, keep_trace=False, _final_keep=keep)[-1]
             return x_0_pred, x_t, x_t_prev, x_t_prev_pred, t
         M, L = mel.shape[2], mel.shape[1]
         t = self._randint(B, dev)
