@@ -241,6 +241,29 @@ int mg_attention_fwd(const float *qkv, const uint8_t *key_pad, float *out, int B
 int mg_layernorm_cm_fwd(const float *a, const float *res, const float *gamma, const float *beta,
                         const uint8_t *pad, float *out, int B, int C, int L, float eps, void *stream);
 
+/* ------------------------------------------------------------------ linguistic-encoder index ops
+ * Device versions of the four functions of the LinguisticEncoder that loop over the batch in
+ * Python with one .item() per phoneme.  Durations / counts are int64 like the reference's LongTensors.
+ * LengthRegulator (model/linguistic_encoder.py:383-416): x [B,Tw,H], dur [B,Tw] (negative = 0) ->
+ * out [B,Lmax,H] (rows past the expanded length are zero, longer expansions are cropped), mel_len [B]. */
+int mg_length_regulate_fwd(const float *x, const int64_t *dur, float *out, int64_t *mel_len, int B,
+                           int Tw, int H, int Lmax, void *stream);
+int mg_length_regulate_bwd(const float *dout, const int64_t *dur, float *dx, int B, int Tw, int H,
+                           int Lmax, void *stream);
+/* word_level_pooling (utils/tools.py:394-413): src [B,Tp,H], wb [B,Tw] phones per word,
+ * src_w_len [B] -> out [B,Wout,H] (sum, or mean when mean != 0). */
+int mg_word_pool_fwd(const float *src, const int64_t *wb, const int64_t *src_w_len, float *out, int B,
+                     int Tp, int Tw, int H, int Wout, int mean, void *stream);
+int mg_word_pool_bwd(const float *dout, const int64_t *wb, const int64_t *src_w_len, float *dsrc, int B,
+                     int Tp, int Tw, int H, int Wout, int mean, void *stream);
+/* get_mapping_mask (model/linguistic_encoder.py:185-199): out uint8 [B,Lq,Lkv], 1 inside the
+ * (frames of word i) x (phonemes of word i) blocks. */
+int mg_mapping_mask(const int64_t *dur_w, const int64_t *wb, const int64_t *src_w_len, uint8_t *out,
+                    int B, int Tw, int Lq, int Lkv, void *stream);
+/* get_rel_coef (model/linguistic_encoder.py:222-236): mask uint8 [B,Lout] (1 = valid) -> out [B,Lout]. */
+int mg_rel_coef(const int64_t *dur, const int64_t *dur_len, const uint8_t *mask, float *out, int B, int T,
+                int Lout, void *stream);
+
 /* ------------------------------------------------------------------ measurement hooks (bench.py)
  * While a session is open, mg_denoiser_fwd brackets each launch of its dominant kernel (the k=3
  * gated convolution of a residual layer) with HIP events recorded on the launch stream.

@@ -18,6 +18,8 @@ EXPORTS = (
     "mg_profile_begin", "mg_profile_begin_sampled", "mg_profile_end", "mg_transpose_bml_strided", "mg_act_bwd", "mg_upsample_zero",
     "mg_step_mlp_fwd", "mg_step_mlp_bwd", "mg_linear_small_fwd", "mg_linear_small_bwd",
     "mg_loss_sum", "mg_loss_grad", "mg_mel_l1_fwd", "mg_mel_l1_bwd", "mg_attention_fwd", "mg_layernorm_cm_fwd",
+    "mg_length_regulate_fwd", "mg_length_regulate_bwd", "mg_word_pool_fwd", "mg_word_pool_bwd", "mg_mapping_mask",
+    "mg_rel_coef",
 )
 
 
@@ -96,6 +98,12 @@ def _declare(L):
         "mg_mel_l1_bwd": (i, [vp, vp, vp, i, i, vp, vp, vp, vp]),
         "mg_attention_fwd": (i, [vp, vp, vp, i, i, i, i, f, vp]),
         "mg_layernorm_cm_fwd": (i, [vp, vp, vp, vp, vp, vp, i, i, i, f, vp]),
+        "mg_length_regulate_fwd": (i, [vp, vp, vp, vp, i, i, i, i, vp]),
+        "mg_length_regulate_bwd": (i, [vp, vp, vp, i, i, i, i, vp]),
+        "mg_word_pool_fwd": (i, [vp, vp, vp, vp, i, i, i, i, i, i, vp]),
+        "mg_word_pool_bwd": (i, [vp, vp, vp, vp, i, i, i, i, i, i, vp]),
+        "mg_mapping_mask": (i, [vp, vp, vp, vp, i, i, i, i, vp]),
+        "mg_rel_coef": (i, [vp, vp, vp, vp, i, i, i, vp]),
         "mg_profile_begin": (i, [i]),
         "mg_profile_begin_sampled": (i, [i, i]),
         "mg_profile_end": (i, [vp, i]),

@@ -367,3 +367,66 @@ def coarse_mel(W, x, pad_mask, max_seq_len, n_layers=6, n_head=2):
     h = decoder_forward(W, "decoder.", x, pad_mask, max_seq_len, n_layers, n_head)
     m = F.linear(h, W["mel_linear.weight"], W["mel_linear.bias"])
     return postnet_forward(W, "postnet.", m) + m
+
+
+# ----------------------------------------------------------------------------- linguistic-encoder index ops
+# (the four host-loop functions of the out-of-scope LinguisticEncoder that
+#  serialise the GPU with one .item() per phoneme.  Plain loops here, like the reference.)
+def word_level_pooling(src_seq, src_len, wb, src_w_len, reduce="sum"):
+    """utils/tools.py:394-413.  src_seq [B,Tp,H]; wb [B,Tw] phones per word -> [B, max(src_w_len), H]."""
+    outs = []
+    for s, sl, w, wl in zip(src_seq, src_len, wb, src_w_len):
+        sizes = [int(v) for v in w[: int(wl)]]
+        rows, p = [], 0
+        for n in sizes:
+            seg = s[p:p + n]
+            acc = torch.zeros_like(s[0])
+            for r in seg:                      # in-order accumulation, as torch.sum over the padded dim
+                acc = acc + r
+            rows.append(acc / n if reduce == "mean" else acc)
+            p += n
+        outs.append(torch.stack(rows) if rows else s.new_zeros(0, s.shape[1]))
+    Wm = max(o.shape[0] for o in outs)
+    return torch.stack([F.pad(o, (0, 0, 0, Wm - o.shape[0])) for o in outs])
+
+
+def length_regulate(x, duration, max_len=None):
+    """model/linguistic_encoder.py:383-416.  x [B,Tw,H], duration [B,Tw] -> ([B,Lmax,H], mel_len int64 [B])."""
+    outs, lens = [], []
+    for xb, db in zip(x, duration):
+        rows = [xb[i].expand(max(int(db[i]), 0), -1) for i in range(xb.shape[0])]
+        e = torch.cat(rows, 0)
+        outs.append(e)
+        lens.append(e.shape[0])
+    Lm = max_len if max_len else max(lens)
+    outs = [F.pad(e, (0, 0, 0, Lm - e.shape[0])) for e in outs]     # negative pad crops, as F.pad does
+    return torch.stack(outs), torch.tensor(lens, dtype=torch.long)
+
+
+def mapping_mask(Lq, Lkv, dur_w, wb, src_w_len):
+    """model/linguistic_encoder.py:185-199: True inside the (frames of word i) x (phonemes of word i) blocks."""
+    B = dur_w.shape[0]
+    m = torch.ones(B, Lq, Lkv)
+    for b in range(B):
+        l = int(src_w_len[b])
+        cw = [0] + [int(v) for v in torch.cumsum(dur_w[b, :l], 0)]
+        cp = [0] + [int(v) for v in torch.cumsum(wb[b, :l], 0)]
+        for i in range(1, len(cw)):
+            m[b, cw[i - 1]:cw[i], cp[i - 1]:cp[i]] = 0
+    return m == 0.0
+
+
+def rel_coef(dur, dur_len, mask):
+    """model/linguistic_encoder.py:222-236: position-in-segment / segment length, 0 on padding."""
+    idx, seg = [], []
+    for d, dl in zip(dur, dur_len):
+        d = d[: int(dl)].long()
+        seg.append(torch.repeat_interleave(d, d))
+        ib = []
+        for di in d:
+            ib += list(range(int(di)))
+        idx.append(torch.tensor(ib, dtype=torch.long))
+    Lm = max(i.shape[0] for i in idx)
+    pi = torch.stack([F.pad(i, (0, Lm - i.shape[0])) for i in idx])
+    ps = torch.stack([F.pad(s_, (0, Lm - s_.shape[0])) for s_ in seg])
+    return torch.div(pi, ps.masked_fill(mask == 0.0, 1))

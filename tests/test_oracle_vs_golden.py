@@ -196,3 +196,27 @@ def test_decoder_and_postnet(manifest):
     W, ck = seeded(manifest, "postnet", 53)
     np.testing.assert_allclose(ck, g["wsum"], rtol=1e-12)
     assert_close(R.postnet_forward(W, "", T(g["x"])), g["out"], 5e-6, "postnet")
+
+
+def test_lingops_index_functions():
+    """word_level_pooling, LengthRegulator, get_mapping_mask, get_rel_coef."""
+    g = golden("lingops")
+    src = T(g["src_seq"]).requires_grad_()
+    src_len, wb, swl = T(g["src_len"]), T(g["wb"]), T(g["src_w_len"])
+    for red in ("sum", "mean"):
+        o = R.word_level_pooling(src, src_len, wb, swl, red)
+        assert torch.equal(o.detach(), T(g["pool_" + red])), red
+        src.grad = None
+        (o * T(g["pool_%s_gw" % red])).sum().backward()
+        assert_close(src.grad, g["pool_%s_dsrc" % red], 1e-6, "pool grad " + red)
+    xw, dur = T(g["xw"]).requires_grad_(), T(g["dur_w"])
+    for tag, ml in (("auto", None), ("max20", 20), ("crop12", 12)):
+        o, lens = R.length_regulate(xw, dur, ml)
+        assert torch.equal(o.detach(), T(g["lr_" + tag])) and torch.equal(lens, T(g["lr_%s_len" % tag])), tag
+        xw.grad = None
+        (o * T(g["lr_%s_gw" % tag])).sum().backward()
+        assert_close(xw.grad, g["lr_%s_dx" % tag], 1e-6, "LR grad " + tag)
+    mm = R.mapping_mask(g["mapping_mask"].shape[1], g["mapping_mask"].shape[2], dur, wb, swl)
+    assert torch.equal(mm, T(g["mapping_mask"]))
+    assert torch.equal(R.rel_coef(dur, swl, T(g["mel_mask"])), T(g["rel_coef_q"]))
+    assert torch.equal(R.rel_coef(wb, swl, T(g["src_mask"])), T(g["rel_coef_kv"]))

@@ -383,6 +383,45 @@ def main():
         y = pn(x)
     save("postnet", x=x, out=y, wsum=ck)
 
+    # (f1) host-loop index ops of the linguistic encoder ---------------------------------------------
+    print("lingops")
+    from model.linguistic_encoder import LinguisticEncoder, LengthRegulator
+    from utils.tools import word_level_pooling, get_mask_from_lengths
+    B, Hd = 3, 256
+    src_w_len = torch.tensor([5, 3, 4])
+    wb = torch.tensor([[2, 1, 3, 1, 2], [4, 2, 1, 0, 0], [1, 1, 5, 2, 0]])          # phones per word
+    src_len = wb.sum(1)
+    Tp = int(src_len.max())
+    src_seq = torch.from_numpy(rng.standard_normal((B, Tp, Hd)).astype(np.float32)).requires_grad_()
+    arrs = dict(src_seq=src_seq, src_len=src_len, wb=wb, src_w_len=src_w_len)
+    for red in ("sum", "mean"):
+        o = word_level_pooling(src_seq, src_len, wb, src_w_len, reduce=red)
+        gw = torch.from_numpy(rng.standard_normal(tuple(o.shape)).astype(np.float32))
+        src_seq.grad = None
+        (o * gw).sum().backward()
+        arrs.update({"pool_" + red: o, "pool_" + red + "_gw": gw, "pool_" + red + "_dsrc": src_seq.grad.clone()})
+    dur_w = torch.tensor([[3, 0, 7, 2, 4], [6, 1, 2, 0, 0], [2, 5, 1, 3, 0]])       # frames per word
+    xw = torch.from_numpy(rng.standard_normal((B, 5, Hd)).astype(np.float32)).requires_grad_()
+    lr = LengthRegulator()
+    for tag, ml in (("auto", None), ("max20", 20), ("crop12", 12)):
+        o, ml_out = lr(xw, dur_w, ml)
+        gw = torch.from_numpy(rng.standard_normal(tuple(o.shape)).astype(np.float32))
+        xw.grad = None
+        (o * gw).sum().backward()
+        arrs.update({"lr_%s" % tag: o, "lr_%s_len" % tag: ml_out, "lr_%s_gw" % tag: gw, "lr_%s_dx" % tag: xw.grad.clone()})
+    arrs.update(dur_w=dur_w, xw=xw)
+    mel_len = dur_w.sum(1)
+    Lq = int(mel_len.max())
+    q = torch.zeros(B, Lq, 4)
+    kv = torch.zeros(B, Tp, 4)
+    arrs["mapping_mask"] = LinguisticEncoder.get_mapping_mask(None, q, kv, dur_w, wb, src_w_len)
+    mel_mask = get_mask_from_lengths(mel_len)                  # True = valid (utils/tools.py:144-153)
+    src_mask = get_mask_from_lengths(src_len)
+    arrs["rel_coef_q"] = LinguisticEncoder.get_rel_coef(None, dur_w, src_w_len, mel_mask)
+    arrs["rel_coef_kv"] = LinguisticEncoder.get_rel_coef(None, wb, src_w_len, src_mask)
+    arrs.update(mel_mask=mel_mask, src_mask=src_mask)
+    save("lingops", **arrs)
+
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(MANIFEST, f, indent=0, sort_keys=True)
     print("manifest written")
