@@ -86,5 +86,52 @@ def main():
         torch.cuda.empty_cache()
 
 
+def lingops_bench():
+    """the four index ops at B=16, ~64 words, ~1000 frames per utterance --
+    device kernels vs the reference-style Python loops (oracle/refmath.py) run on the same GPU tensors
+    (every int(...) in those loops is a device->host sync, as in the reference)."""
+    from oracle import refmath as R
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator().manual_seed(17)
+    B, Tw, H = 16, 64, 256
+    swl = torch.full((B,), Tw, dtype=torch.long)
+    wb = torch.randint(1, 5, (B, Tw), generator=gen)
+    dur = torch.randint(8, 24, (B, Tw), generator=gen)
+    src_len = wb.sum(1)
+    Tp = int(src_len.max())
+    src = torch.randn(B, Tp, H, generator=gen).to(dev)
+    xw = torch.randn(B, Tw, H, generator=gen).to(dev)
+    wb, dur, swl, src_len = wb.to(dev), dur.to(dev), swl.to(dev), src_len.to(dev)
+    L = mg.lingops
+    lr = L.LengthRegulator()
+    o, ml = lr(xw, dur, None)
+    Lq = o.shape[1]
+    mel_mask = torch.arange(Lq, device=dev)[None, :] < ml[:, None]
+    q, kv = torch.zeros(B, Lq, 1, device=dev), torch.zeros(B, Tp, 1, device=dev)
+
+    def ours():
+        L.word_level_pooling(src, src_len, wb, swl, "mean", max_words=Tw)
+        lr(xw, dur, Lq)
+        L.get_mapping_mask(q, kv, dur, wb, swl)
+        L.get_rel_coef(dur, swl, mel_mask)
+
+    def loops():
+        R.word_level_pooling(src, src_len, wb, swl, "mean")
+        R.length_regulate(xw, dur, Lq)
+        R.mapping_mask(Lq, Tp, dur, wb, swl).to(dev)
+        R.rel_coef(dur.cpu(), swl.cpu(), mel_mask.cpu())  # (its index lists are host-built, as in the reference)
+
+    t_ours = timeit(ours, 3, 50)
+    t_loops = timeit(loops, 1, 3)
+    bytes_moved = (src.numel() + B * Tw * H) * 4 + (xw.numel() + o.numel()) * 4 + B * Lq * Tp + B * Lq * 4
+    print(json.dumps({"config": "f1 index ops, B=16, 64 words, %d phonemes, %d frames" % (Tp, Lq),
+                      "device_kernels_us": round(t_ours * 1e6, 1), "python_loops_ms": round(t_loops * 1e3, 1),
+                      "speedup": round(t_loops / t_ours, 1), "algorithmic_MB": round(bytes_moved / 1e6, 1),
+                      "GBps": round(bytes_moved / t_ours / 1e9, 1)}), flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "lingops":
+        lingops_bench()
+    else:
+        main()
