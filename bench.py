@@ -54,6 +54,9 @@ def main():
                     help="fp32: exact fp32 MFMA (headline). bf16x3: residual-layer GEMMs as 3-term bf16-split MFMA "
                          "products with fp32 accumulate (opt-in, parity 2e-4); reported under 'alt'")
     ap.add_argument("--no-alt", action="store_true", help="skip the second measurement in the other precision")
+    ap.add_argument("--workload", choices=["denoise", "train"], default="denoise",
+                    help="denoise: the BASELINE metric (default).  train: BASELINE configs[3] -- multi-speaker naive GAN "
+                         "training step (G+D), global batch 8*N sharded over N ranks, gradients all-reduced over RCCL")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -79,6 +82,9 @@ def main():
     import mixgan_tts_amd as mg
     from mixgan_tts_amd import ops, _lib
     from helpers import hot_path_configs, write_stats
+
+    if args.workload == "train":
+        return train_workload(args, mg, dev, dist, rank, world)
 
     B, L = args.batch, args.frames
     with tempfile.TemporaryDirectory() as d:
@@ -199,6 +205,66 @@ def main():
             line["cpu_baseline"] = cpu_baseline(gd, B, L)
             line["speedup_vs_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def train_workload(args, mg, dev, dist, rank, world):
+    """BASELINE configs[3]: multi-speaker naive training step, per-rank batch 8 (global 64 at N=8), L=1000.
+    One step = D phase + G phase of train.py:91-184 on the hot path (synthetic conditioner standing in for the
+    linguistic encoder), both optimizers, gradient all-reduce (mean) per optimizer before clipping."""
+    from helpers import hot_path_configs, write_stats
+    B, L = (8 if args.batch == B_PER_GPU else args.batch), args.frames
+    with tempfile.TemporaryDirectory() as d:
+        stats = write_stats(d, [-11.5] * MEL, [2.0] * MEL, n_speakers=218)
+        a, pre, mc, tr = hot_path_configs("naive", 4, multi_speaker=True, stats_dir=stats)
+        G = mg.GaussianDiffusion(a, pre, mc, tr)
+        D = mg.JCUDiscriminator(pre, mc, tr)
+    gen = torch.Generator().manual_seed(1234)          # identical initial weights on every rank
+    with torch.no_grad():
+        for p in list(G.parameters()) + list(D.parameters()):
+            fan = p[0].numel() if p.dim() > 1 else 1
+            p.copy_(torch.randn(p.shape, generator=gen) * (fan ** -0.5 if p.dim() > 1 else 0.1))
+    G, D = G.to(dev), D.to(dev)
+    trainer = mg.HotPathTrainer(G, D, tr, mc)
+    rng = np.random.default_rng(1234 + rank)            # rank-distinct data shard
+    mel = torch.from_numpy(rng.uniform(-11.5, 2.0, (B, L, MEL)).astype(np.float32)).to(dev)
+    cond = torch.from_numpy(rng.standard_normal((B, L, 256)).astype(np.float32)).to(dev)
+    spk = torch.from_numpy(rng.standard_normal((B, 256)).astype(np.float32)).to(dev)
+    pad = torch.zeros(B, L, dtype=torch.bool, device=dev)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(mel, cond, spk, pad)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trainer.step(mel, cond, spk, pad)
+    sync()
+    dt = time.perf_counter() - t0
+    assert all(torch.isfinite(v).all() for v in out.values())
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        # per step: 2 denoiser forwards + 1 backward (= 4 forward-equivalents), 4 D forwards + 2 backward passes
+        flop = (4 * FLOP_PER_FRAME + 8 * 645504.0) * B * L * world
+        print(json.dumps({
+            "metric": "GAN train steps/sec (hot path: GaussianDiffusion + JCUDiscriminator, G+D optimizers)",
+            "value": round(args.steps / dt, 3), "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: multi-speaker naive train step, batch %d/GPU (global %d), L=%d, "
+                                   "T=4" % (B, B * world, L),
+                       "parallelism": "dp%d, flat-bucket gradient all-reduce (G 99 MB, D 8 MB) per optimizer" % world},
+            "samples_per_s": round(B * world * args.steps / dt, 2),
+            "approx_tflops": round(flop * args.steps / dt / 1e12, 1)}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
