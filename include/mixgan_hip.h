@@ -41,6 +41,7 @@ const char *mg_error_string(int code);
 #define MG_ACT_RELU 1
 #define MG_ACT_LRELU02 2 /* F.leaky_relu(x, 0.2): model/mixgantts.py:273,282,286 */
 #define MG_ACT_TANH 3
+#define MG_ACT_LRELU 4 /* leaky ReLU with a caller-given slope (HiFi-GAN: hifigan/models.py:7,95,150,161) */
 
 /* ------------------------------------------------------------------ Conv1d / Linear as MFMA GEMM
  * Stands in for every nn.Conv1d / nn.Linear on the path (ConvNorm model/blocks.py:364-371,
@@ -90,6 +91,15 @@ int mg_conv1d_wgrad_strided(const float *dy, long dy_bs, const float *x, long x_
  * channel sums.  out_r[r] (+)= alpha*sum_{b,l} (may be NULL); out_br[b,r] = alpha*sum_l (may be NULL). */
 int mg_rowsum(const float *in, long in_bs, int B, int R, int L, float *out_r, float *out_br,
               float alpha, int accumulate, void *stream);
+
+/* Extended form for the vocoder (hifigan/models.py): K additionally in {4,7,11,16},
+ * dilation dil <= 5 (input sample l*stride + k*dil - pad), a leaky ReLU of slope in_slope applied to the
+ * input samples while they are staged (1 = identity; pre-activation of ResBlock convs), and
+ * act = MG_ACT_LRELU with slope act_slope. */
+int mg_conv1d_fwd_ex(const float *in, const float *in_vec, const float *packed, const float *bias,
+                     const float *add, float *out, int B, int Ci, int Lin, int Co, int Lout, int K,
+                     int stride, int pad, int dil, float in_slope, int act, float act_slope, float alpha,
+                     int accumulate, void *stream);
 
 /* ------------------------------------------------------------------ diffusion algebra (HBM-bound)
  * Schedule tables are the fp32 buffers of GaussianDiffusion (model/diffusion.py:60-83). */
@@ -200,6 +210,10 @@ int mg_act_bwd(const float *dy, const float *y, float *out, int act, size_t n, v
 /* Zero insertion out[r, j] = in[r, j/stride] if stride | j else 0 (j < Lup): turns the data gradient
  * of a strided Conv1d (model/mixgantts.py:219-228, strides [1,2,2]) into a stride-1 convolution. */
 int mg_upsample_zero(const float *in, float *out, int rows, int Lin, int stride, int Lup, void *stream);
+/* Same with a leaky ReLU (slope) on the kept samples: lrelu + ConvTranspose1d of hifigan/models.py:150-151 as
+ * zero insertion followed by a stride-1 convolution on the MG_PACK_DGRAD pack of the [Cin, Cout, K] weight. */
+int mg_upsample_zero_act(const float *in, float *out, int rows, int Lin, int stride, int Lup, float slope,
+                         void *stream);
 
 /* Step-embedding MLP: out = W2 mish(W0 [sin|cos](t * freq)).  Denoiser: model/modules.py:398-403,434;
  * JCUDiscriminator: model/mixgantts.py:203-208,265.  emb [B,D0], pre/h [B,D1] are saved for backward. */

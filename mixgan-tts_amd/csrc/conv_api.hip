@@ -40,7 +40,8 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, float *__restrict_
 
 static int pack_dims(int Co, int Ci, int K, int mode, int *Mrows, int *Kin, int *MB)
 {
-    if (Co <= 0 || Ci <= 0 || !(K == 1 || K == 3 || K == 5 || K == 9)) return MG_ERR_SHAPE;
+    if (Co <= 0 || Ci <= 0 || !(K == 1 || K == 3 || K == 4 || K == 5 || K == 7 || K == 9 || K == 11 || K == 16))
+        return MG_ERR_SHAPE;
     if (mode == MG_PACK_PLAIN) {
         *Mrows = Co;
         *Kin = Ci;
@@ -96,16 +97,28 @@ extern "C" int mg_conv_pack(const float *w, float *packed, int Co, int Ci, int K
     return mg_conv_pack_at(w, packed, Co, Ci, K, mode, 0, Q, stream);
 }
 
+template <>
+struct EpiWide<EpiBiasAct> { static constexpr bool value = true; };
+
+extern "C" int mg_conv1d_fwd_ex(const float *in, const float *in_vec, const float *packed, const float *bias,
+                                const float *add, float *out, int B, int Ci, int Lin, int Co, int Lout, int K,
+                                int stride, int pad, int dil, float in_slope, int act, float act_slope, float alpha,
+                                int accumulate, void *stream)
+{
+    if (!in || !packed || !out) return MG_ERR_ARG;
+    if (act < 0 || act > MG_ACT_LRELU) return MG_ERR_ARG;
+    if (B <= 0 || Ci <= 0 || Co <= 0 || Lin <= 0 || Lout <= 0 || pad < 0 || dil < 1) return MG_ERR_SHAPE;
+    ConvShape s{B, Ci, Lin, Lout, K, stride, pad, Co, 0, 0, dil, in_slope};
+    EpiBiasAct::Params ep{out, bias, add, alpha, Co, act, accumulate, 0, nullptr, act_slope};
+    return conv_launch<EpiBiasAct>(s, in, in_vec, packed, ep, (hipStream_t)stream);
+}
+
 extern "C" int mg_conv1d_fwd(const float *in, const float *in_vec, const float *packed, const float *bias,
                              const float *add, float *out, int B, int Ci, int Lin, int Co, int Lout, int K, int stride,
                              int pad, int act, float alpha, int accumulate, void *stream)
 {
-    if (!in || !packed || !out) return MG_ERR_ARG;
-    if (act < 0 || act > MG_ACT_TANH) return MG_ERR_ARG;
-    if (B <= 0 || Ci <= 0 || Co <= 0 || Lin <= 0 || Lout <= 0 || pad < 0) return MG_ERR_SHAPE;
-    ConvShape s{B, Ci, Lin, Lout, K, stride, pad, Co, 0, 0};
-    EpiBiasAct::Params ep{out, bias, add, alpha, Co, act, accumulate, 0, nullptr};
-    return conv_launch<EpiBiasAct>(s, in, in_vec, packed, ep, (hipStream_t)stream);
+    return mg_conv1d_fwd_ex(in, in_vec, packed, bias, add, out, B, Ci, Lin, Co, Lout, K, stride, pad, 1, 1.f, act, 0.f,
+                            alpha, accumulate, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

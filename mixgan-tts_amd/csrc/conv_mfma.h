@@ -32,6 +32,8 @@ struct ConvArgs {
     int in_rs;            // row (channel) stride of `in` (floats), normally Lin
     int B, Ci, CiP, Lin, Lout, pad;
     int ntiles_per_b, ntiles_total;
+    int dil;              // dilation (<= DILMAX of the instantiation)
+    float in_slope;       // leaky-ReLU slope applied to the input samples while staging (1 = identity)
 };
 
 // number of k-groups (8 channels x 1 tap) per 32-row block
@@ -54,6 +56,7 @@ struct EpiBiasAct {
         int accumulate;    // out += result
         long out_bs;       // batch stride of out (0 -> Co*Lout): lets the output be a channel slice
         const float *mask; // optional [B, Co, Lout] dense: result *= (mask > 0)   (ReLU backward)
+        float act_slope;   // slope of MG_ACT_LRELU
     };
     template <int WM, int NNB>
     static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][NNB], int b, int mrow0, int l0w,
@@ -80,6 +83,7 @@ struct EpiBiasAct {
                         case MG_ACT_RELU: v = mg_act<MG_ACT_RELU>(v); break;
                         case MG_ACT_LRELU02: v = mg_act<MG_ACT_LRELU02>(v); break;
                         case MG_ACT_TANH: v = mg_act<MG_ACT_TANH>(v); break;
+                        case MG_ACT_LRELU: v = v > 0.f ? v : p.act_slope * v; break;
                         default: break;
                         }
                         if (arow) v += arow[l];
@@ -94,11 +98,11 @@ struct EpiBiasAct {
 };
 
 // ---------------------------------------------------------------------------------------------
-template <int KW, int STRIDE, int CK, int WM, int NNB, class Epi>
+template <int KW, int STRIDE, int CK, int DILMAX, int WM, int NNB, class Epi>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, typename Epi::Params ep)
 {
     constexpr int NT = 64 * NNB;  // output frames per workgroup: 2 (N) waves x NNB 32-frame blocks
-    constexpr int TW = NT * STRIDE + KW - 1;  // input frames per tile row (>= (NT-1)*STRIDE + KW)
+    constexpr int TW = NT * STRIDE + (KW - 1) * DILMAX;  // input frames per tile row (taps at multiples of a.dil)
     constexpr int TILE = CK * TW;
     constexpr int NLD = (TILE + 255) / 256;
     constexpr int QC = KW * (CK / 8);  // k-groups per chunk
@@ -149,6 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, typename 
             if (idx < TILE && ci < a.Ci && l >= 0 && l < a.Lin) {
                 v = inb[(size_t)ci * a.in_rs + l];
                 if (a.in_vec) v += a.in_vec[(size_t)b * a.Ci + ci];
+                v = v > 0.f ? v : v * a.in_slope;
             }
             stage[k] = v;
         }
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, typename 
                     const int s = g * 4 + e;
                     float bv[NNB];
 #pragma unroll
-                    for (int j = 0; j < NNB; ++j) bv[j] = L[boff + (2 * s) * TW + tap + 32 * j * STRIDE];
+                    for (int j = 0; j < NNB; ++j) bv[j] = L[boff + (2 * s) * TW + (DILMAX > 1 ? tap * a.dil : tap) + 32 * j * STRIDE];
 #pragma unroll
                     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -212,9 +217,11 @@ struct ConvShape {
     int B, Ci, Lin, Lout, K, stride, pad, Mrows;
     long in_bs;  // 0 -> Ci*Lin
     int in_rs;   // 0 -> Lin
+    int dil = 1;
+    float in_slope = 1.f;
 };
 
-template <int KW, int STRIDE, int CK, int WM, int NNB, class Epi>
+template <int KW, int STRIDE, int CK, int DILMAX, int WM, int NNB, class Epi>
 static int conv_launch_t(const ConvShape &s, const float *in, const float *in_vec, const float *wp,
                          const typename Epi::Params &ep, hipStream_t st)
 {
@@ -230,11 +237,13 @@ static int conv_launch_t(const ConvShape &s, const float *in, const float *in_ve
     a.Lin = s.Lin;
     a.Lout = s.Lout;
     a.pad = s.pad;
+    a.dil = s.dil;
+    a.in_slope = s.in_slope;
     a.ntiles_per_b = mg_cdiv(s.Lout, 64 * NNB);
     a.ntiles_total = a.ntiles_per_b * s.B;
     const int mtiles = mg_cdiv(s.Mrows, 64 * WM);
     dim3 grid((unsigned)(a.ntiles_total * mtiles));
-    hipLaunchKernelGGL((conv_mfma_kernel<KW, STRIDE, CK, WM, NNB, Epi>), grid, dim3(256), 0, st, a, ep);
+    hipLaunchKernelGGL((conv_mfma_kernel<KW, STRIDE, CK, DILMAX, WM, NNB, Epi>), grid, dim3(256), 0, st, a, ep);
     MG_LAUNCH_CHECK();
     return MG_OK;
 }
@@ -245,7 +254,7 @@ static int conv_launch_t(const ConvShape &s, const float *in, const float *in_ve
 template <class Epi>
 struct EpiNeedsWM2 { static constexpr bool value = false; };
 
-template <int KW, int STRIDE, int CK, class Epi>
+template <int KW, int STRIDE, int CK, int DILMAX, class Epi>
 static int conv_launch_k(const ConvShape &s, const float *in, const float *in_vec, const float *wp,
                          const typename Epi::Params &ep, hipStream_t st)
 {
@@ -257,25 +266,37 @@ static int conv_launch_k(const ConvShape &s, const float *in, const float *in_ve
     if (wgs(wm, nnb) < 512) nnb = 1;
     if (wgs(wm, nnb) < 512 && wm == 2 && can_wm1) wm = 1;
     if (wm == 2)
-        return nnb == 2 ? conv_launch_t<KW, STRIDE, CK, 2, 2, Epi>(s, in, in_vec, wp, ep, st)
-                        : conv_launch_t<KW, STRIDE, CK, 2, 1, Epi>(s, in, in_vec, wp, ep, st);
-    return nnb == 2 ? conv_launch_t<KW, STRIDE, CK, 1, 2, Epi>(s, in, in_vec, wp, ep, st)
-                    : conv_launch_t<KW, STRIDE, CK, 1, 1, Epi>(s, in, in_vec, wp, ep, st);
+        return nnb == 2 ? conv_launch_t<KW, STRIDE, CK, DILMAX, 2, 2, Epi>(s, in, in_vec, wp, ep, st)
+                        : conv_launch_t<KW, STRIDE, CK, DILMAX, 2, 1, Epi>(s, in, in_vec, wp, ep, st);
+    return nnb == 2 ? conv_launch_t<KW, STRIDE, CK, DILMAX, 1, 2, Epi>(s, in, in_vec, wp, ep, st)
+                    : conv_launch_t<KW, STRIDE, CK, DILMAX, 1, 1, Epi>(s, in, in_vec, wp, ep, st);
 }
 
-// Dispatch on (K, stride); CK must match mg_conv_ck().
+// Dispatch on (K, stride, dilation); CK must match mg_conv_ck().  The path's own convolutions (K in
+// {1,3,5,9}, dilation 1) are always instantiated; the vocoder shapes (K in {7,11,16,4}, dilations up to 5:
+// hifigan/models.py:19-95,112-143) only for epilogues that opt in (EpiWide), to keep build time down.
+template <class Epi>
+struct EpiWide { static constexpr bool value = false; };
+
 template <class Epi>
 static int conv_launch(const ConvShape &s, const float *in, const float *in_vec, const float *wp,
                        const typename Epi::Params &ep, hipStream_t st)
 {
-    if (s.B <= 0 || s.Lout <= 0 || s.Ci <= 0 || s.Mrows <= 0) return MG_ERR_SHAPE;
-#define MG_CONV_CASE(KW_, ST_, CK_) \
-    if (s.K == KW_ && s.stride == ST_) return conv_launch_k<KW_, ST_, CK_, Epi>(s, in, in_vec, wp, ep, st);
-    MG_CONV_CASE(1, 1, 32)
-    MG_CONV_CASE(3, 1, 32)
-    MG_CONV_CASE(5, 1, 16)
-    MG_CONV_CASE(9, 1, 16)
-    MG_CONV_CASE(5, 2, 16)
+    if (s.B <= 0 || s.Lout <= 0 || s.Ci <= 0 || s.Mrows <= 0 || s.dil < 1) return MG_ERR_SHAPE;
+#define MG_CONV_CASE(KW_, ST_, CK_, DM_) \
+    if (s.K == KW_ && s.stride == ST_ && s.dil <= DM_) return conv_launch_k<KW_, ST_, CK_, DM_, Epi>(s, in, in_vec, wp, ep, st);
+    MG_CONV_CASE(1, 1, 32, 1)
+    MG_CONV_CASE(3, 1, 32, 1)
+    MG_CONV_CASE(5, 1, 16, 1)
+    MG_CONV_CASE(9, 1, 16, 1)
+    MG_CONV_CASE(5, 2, 16, 1)
+    if constexpr (EpiWide<Epi>::value) {
+        MG_CONV_CASE(3, 1, 32, 5)
+        MG_CONV_CASE(7, 1, 16, 5)
+        MG_CONV_CASE(11, 1, 16, 5)
+        MG_CONV_CASE(16, 1, 16, 1)
+        MG_CONV_CASE(4, 1, 16, 1)
+    }
 #undef MG_CONV_CASE
     return MG_ERR_SHAPE;
 }

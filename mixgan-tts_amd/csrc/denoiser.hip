@@ -327,7 +327,7 @@ extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, c
         MG_LAUNCH_CHECK();
     } else {
         ConvShape s{B, M, L, L, 1, 1, 0, C, 0, 0};
-        EpiBiasAct::Params ep{ws + w.x0, packed + o.in_b, nullptr, 1.f, C, MG_ACT_RELU, 0, 0, nullptr};
+        EpiBiasAct::Params ep{ws + w.x0, packed + o.in_b, nullptr, 1.f, C, MG_ACT_RELU, 0, 0, nullptr, 0.f};
         MG_TRY(conv_launch<EpiBiasAct>(s, x_t, nullptr, packed + o.in_w, ep, st));
     }
     if (split) {
@@ -441,12 +441,12 @@ extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, c
     }
     {
         ConvShape s{B, C, L, L, 1, 1, 0, C, 0, 0};
-        EpiBiasAct::Params ep{ws + w.y, packed + o.skip_b, nullptr, 1.0f / sqrtf((float)NL), C, MG_ACT_RELU, 0, 0, nullptr};
+        EpiBiasAct::Params ep{ws + w.y, packed + o.skip_b, nullptr, 1.0f / sqrtf((float)NL), C, MG_ACT_RELU, 0, 0, nullptr, 0.f};
         MG_TRY(conv_launch<EpiBiasAct>(s, ws + w.skip, nullptr, packed + o.skip_w, ep, st));
     }
     {
         ConvShape s{B, C, L, L, 1, 1, 0, M, 0, 0};
-        EpiBiasAct::Params ep{out, packed + o.out_b, nullptr, 1.f, M, MG_ACT_NONE, 0, 0, nullptr};
+        EpiBiasAct::Params ep{out, packed + o.out_b, nullptr, 1.f, M, MG_ACT_NONE, 0, 0, nullptr, 0.f};
         MG_TRY(conv_launch<EpiBiasAct>(s, ws + w.y, nullptr, packed + o.out_w, ep, st));
     }
     return MG_OK;

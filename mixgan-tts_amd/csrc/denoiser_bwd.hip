@@ -139,7 +139,7 @@ extern "C" int mg_denoiser_bwd(const mg_denoiser_dims *d, const float *packed, c
     // ---- head: output_projection, ReLU, skip_projection (model/modules.py:441-444) ------------
     {
         ConvShape s{B, M, L, L, 1, 1, 0, C, 0, 0};
-        EpiBiasAct::Params ep{dy, nullptr, nullptr, 1.f, C, MG_ACT_NONE, 0, 0, ws + w.y};
+        EpiBiasAct::Params ep{dy, nullptr, nullptr, 1.f, C, MG_ACT_NONE, 0, 0, ws + w.y, 0.f};
         MG_TRY(conv_launch<EpiBiasAct>(s, g_out, nullptr, packed + o.out_wT, ep, st));
     }
     if (grads[6]) {
@@ -149,7 +149,7 @@ extern "C" int mg_denoiser_bwd(const mg_denoiser_dims *d, const float *packed, c
     if (grads[7]) MG_TRY(rowsum(g_out, 0, B, M, L, grads[7], nullptr, 1.f, st));
     {
         ConvShape s{B, C, L, L, 1, 1, 0, C, 0, 0};
-        EpiBiasAct::Params ep{dout + CL, nullptr, nullptr, rsNL, C, MG_ACT_NONE, 0, (long)(2 * CL), nullptr};
+        EpiBiasAct::Params ep{dout + CL, nullptr, nullptr, rsNL, C, MG_ACT_NONE, 0, (long)(2 * CL), nullptr, 0.f};
         MG_TRY(conv_launch<EpiBiasAct>(s, dy, nullptr, packed + o.skip_wT, ep, st));
     }
     if (grads[4]) {
@@ -209,14 +209,14 @@ extern "C" int mg_denoiser_bwd(const mg_denoiser_dims *d, const float *packed, c
     if (grads[1]) MG_TRY(rowsum(dx0, 0, B, C, L, grads[1], nullptr, 1.f, st));
     if (d_x_t) {
         ConvShape s{B, C, L, L, 1, 1, 0, M, 0, 0};
-        EpiBiasAct::Params ep{d_x_t, nullptr, nullptr, 1.f, M, MG_ACT_NONE, 0, 0, nullptr};
+        EpiBiasAct::Params ep{d_x_t, nullptr, nullptr, 1.f, M, MG_ACT_NONE, 0, 0, nullptr, 0.f};
         MG_TRY(conv_launch<EpiBiasAct>(s, dx0, nullptr, packed + o.in_wT, ep, st));
     }
 
     // ---- conditioner projections, all layers at once -----------------------------------------
     if (d_cond) {
         ConvShape s{B, NL * C, L, L, 1, 1, 0, H, 0, 0};
-        EpiBiasAct::Params ep{d_cond, nullptr, nullptr, 1.f, H, MG_ACT_NONE, 0, 0, nullptr};
+        EpiBiasAct::Params ep{d_cond, nullptr, nullptr, 1.f, H, MG_ACT_NONE, 0, 0, nullptr, 0.f};
         MG_TRY(conv_launch<EpiBiasAct>(s, dh_all, nullptr, packed + o.wc_allT, ep, st));
     }
     if (LG(0, 3)) {

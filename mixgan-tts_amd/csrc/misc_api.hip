@@ -29,27 +29,39 @@ extern "C" int mg_act_bwd(const float *dy, const float *y, float *out, int act, 
     return MG_OK;
 }
 
-// out[r, j] = (j % s == 0 && j/s < Lin) ? in[r, j/s] : 0,   j < Lup
+// out[r, j] = (j % s == 0 && j/s < Lin) ? lrelu(in[r, j/s], slope) : 0,   j < Lup   (slope 1 = identity)
 __global__ void upsample_zero_kernel(const float *__restrict__ in, float *__restrict__ out, int Lin, int s, int Lup,
-                                     size_t n)
+                                     float slope, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t r = i / Lup;
         const int j = (int)(i - r * Lup);
         const int q = j / s;
-        out[i] = (j - q * s == 0 && q < Lin) ? in[r * Lin + q] : 0.f;
+        float v = 0.f;
+        if (j - q * s == 0 && q < Lin) {
+            v = in[r * Lin + q];
+            v = v > 0.f ? v : v * slope;
+        }
+        out[i] = v;
     }
 }
 
-extern "C" int mg_upsample_zero(const float *in, float *out, int rows, int Lin, int stride, int Lup, void *stream)
+extern "C" int mg_upsample_zero_act(const float *in, float *out, int rows, int Lin, int stride, int Lup, float slope,
+                                    void *stream)
 {
     if (!in || !out) return MG_ERR_ARG;
     if (rows <= 0 || Lin <= 0 || stride < 1 || Lup <= 0) return MG_ERR_SHAPE;
     const size_t n = (size_t)rows * Lup;
-    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(upsample_zero_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, Lin, stride, Lup, n);
+    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(upsample_zero_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, Lin, stride, Lup,
+                       slope, n);
     MG_LAUNCH_CHECK();
     return MG_OK;
+}
+
+extern "C" int mg_upsample_zero(const float *in, float *out, int rows, int Lin, int stride, int Lup, void *stream)
+{
+    return mg_upsample_zero_act(in, out, rows, Lin, stride, Lup, 1.f, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

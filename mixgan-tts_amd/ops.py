@@ -7,7 +7,7 @@ import torch
 from . import _lib
 from ._lib import fptr, iptr, check, stream_ptr
 
-ACT = {None: 0, "none": 0, "relu": 1, "lrelu": 2, "tanh": 3}
+ACT = {None: 0, "none": 0, "relu": 1, "lrelu": 2, "tanh": 3, "lrelu_s": 4}
 PACK_PLAIN, PACK_GATE, PACK_DGRAD = 0, 1, 2
 
 
@@ -43,16 +43,18 @@ def pack_cached(w, mode=PACK_PLAIN):
 
 
 def conv1d_packed(x, packed, bias, Co, K, stride=1, padding=0, act=None, alpha=1.0, add=None, in_vec=None,
-                  out=None, accumulate=False, Lout=None):
+                  out=None, accumulate=False, Lout=None, dilation=1, in_slope=1.0, act_slope=0.0):
+    """act: None | "relu" | "lrelu" (0.2) | "tanh" | "lrelu_s" (slope act_slope); in_slope: leaky ReLU
+    applied to the input while staging (1 = identity)."""
     L = _lib.lib()
     B, Ci, Lin = x.shape
     if Lout is None:
-        Lout = (Lin + 2 * padding - K) // stride + 1
+        Lout = (Lin + 2 * padding - dilation * (K - 1) - 1) // stride + 1
     if out is None:
         out = torch.empty(B, Co, Lout, device=x.device, dtype=torch.float32)
-    check(L.mg_conv1d_fwd(fptr(x), fptr(in_vec, True), fptr(packed), fptr(bias, True), fptr(add, True), fptr(out),
-                          B, Ci, Lin, Co, Lout, K, stride, padding, ACT[act], float(alpha),
-                          int(accumulate), stream_ptr()))
+    check(L.mg_conv1d_fwd_ex(fptr(x), fptr(in_vec, True), fptr(packed), fptr(bias, True), fptr(add, True), fptr(out),
+                             B, Ci, Lin, Co, Lout, K, stride, padding, dilation, float(in_slope), ACT[act],
+                             float(act_slope), float(alpha), int(accumulate), stream_ptr()))
     return out
 
 
@@ -158,11 +160,11 @@ def act_bwd(dy, y, act):
     return out
 
 
-def upsample_zero(x, stride, Lup):
+def upsample_zero(x, stride, Lup, slope=1.0):
     L = _lib.lib()
     B, C, Lin = x.shape
     out = torch.empty(B, C, Lup, device=x.device, dtype=torch.float32)
-    check(L.mg_upsample_zero(fptr(x), fptr(out), B * C, Lin, stride, Lup, stream_ptr()))
+    check(L.mg_upsample_zero_act(fptr(x), fptr(out), B * C, Lin, stride, Lup, float(slope), stream_ptr()))
     return out
 
 

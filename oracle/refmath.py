@@ -430,3 +430,42 @@ def rel_coef(dur, dur_len, mask):
     pi = torch.stack([F.pad(i, (0, Lm - i.shape[0])) for i in idx])
     ps = torch.stack([F.pad(s_, (0, Lm - s_.shape[0])) for s_ in seg])
     return torch.div(pi, ps.masked_fill(mask == 0.0, 1))
+
+
+# ----------------------------------------------------------------------------- HiFi-GAN generator (vocoder, row f3)
+HIFIGAN_V1 = dict(upsample_rates=(8, 8, 2, 2), upsample_kernel_sizes=(16, 16, 4, 4), upsample_initial_channel=512,
+                  resblock_kernel_sizes=(3, 7, 11), resblock_dilation_sizes=((1, 3, 5), (1, 3, 5), (1, 3, 5)))
+
+
+def _wn(W, name):
+    """weight_norm (dim=0): w = g * v / ||v|| over all dims but the first; or the plain weight after
+    remove_weight_norm (hifigan/models.py:167-173)."""
+    if name + ".weight" in W:
+        return W[name + ".weight"]
+    v, g = W[name + ".weight_v"], W[name + ".weight_g"]
+    return v * (g / v.flatten(1).norm(dim=1).view(-1, *([1] * (v.dim() - 1))))
+
+
+def hifigan_forward(W, mel, h=HIFIGAN_V1):
+    """hifigan/models.py:145-165.  mel [B, 80, L] -> wav [B, 1, L * prod(upsample_rates)]."""
+    nk = len(h["resblock_kernel_sizes"])
+    x = F.conv1d(mel, _wn(W, "conv_pre"), W["conv_pre.bias"], padding=3)
+    for i, (u, k) in enumerate(zip(h["upsample_rates"], h["upsample_kernel_sizes"])):
+        x = F.leaky_relu(x, 0.1)
+        x = F.conv_transpose1d(x, _wn(W, "ups.%d" % i), W["ups.%d.bias" % i], stride=u, padding=(k - u) // 2)
+        xs = None
+        for j, (ks, dils) in enumerate(zip(h["resblock_kernel_sizes"], h["resblock_dilation_sizes"])):
+            p = "resblocks.%d." % (i * nk + j)
+            r = x
+            for m, d in enumerate(dils):
+                t = F.leaky_relu(r, 0.1)
+                t = F.conv1d(t, _wn(W, p + "convs1.%d" % m), W[p + "convs1.%d.bias" % m], dilation=d,
+                             padding=(ks * d - d) // 2)
+                t = F.leaky_relu(t, 0.1)
+                t = F.conv1d(t, _wn(W, p + "convs2.%d" % m), W[p + "convs2.%d.bias" % m], padding=(ks - 1) // 2)
+                r = t + r
+            xs = r if xs is None else xs + r
+        x = xs / nk
+    x = F.leaky_relu(x)          # default slope 0.01, not LRELU_SLOPE (hifigan/models.py:161)
+    x = F.conv1d(x, _wn(W, "conv_post"), W["conv_post.bias"], padding=3)
+    return torch.tanh(x)

@@ -1,0 +1,104 @@
+"""GPU parity of the HiFi-GAN generator mirror (hifigan/models.py:112-173)
+against the reference-generated fixture and the oracle.  Tolerance: 1e-3 relative (BASELINE north_star)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import golden, assert_close, load_seeded, seeded, T
+from oracle import refmath as R
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def mg():
+    import mixgan_tts_amd
+    return mixgan_tts_amd
+
+
+def _h():
+    return types.SimpleNamespace(**R.HIFIGAN_V1)
+
+
+def _seeded_generator(mg, manifest, g):
+    G = mg.vocoder.Generator(_h())
+    load_seeded(G, manifest, "hifigan", 81)
+    sd = G.state_dict()
+    for k in g:
+        if k.startswith("gain/"):
+            sd[k[5:]] = torch.from_numpy(g[k])
+    G.load_state_dict(sd)
+    return G.cuda().eval()
+
+
+def test_generator_matches_reference_fixture(mg, manifest):
+    g = golden("hifigan")
+    G = _seeded_generator(mg, manifest, g)
+    y = G(torch.from_numpy(g["mel"]).cuda())
+    assert tuple(y.shape) == tuple(g["wav"].shape)
+    assert_close(y.cpu(), g["wav"], TOL, "hifigan Generator")
+    # remove_weight_norm (utils/model.py:124) leaves the function unchanged and the keys as the reference's
+    G.remove_weight_norm()
+    assert "conv_pre.weight" in G.state_dict() and "conv_pre.weight_g" not in G.state_dict()
+    y2 = G(torch.from_numpy(g["mel"]).cuda())
+    assert_close(y2.cpu(), g["wav"], TOL, "hifigan Generator after remove_weight_norm")
+
+
+@pytest.mark.parametrize("B,L", [(1, 1), (3, 37), (1, 200)])
+def test_generator_vs_oracle(mg, manifest, B, L):
+    g = golden("hifigan")
+    G = _seeded_generator(mg, manifest, g)
+    W, _ = seeded(manifest, "hifigan", 81)
+    for k in g:
+        if k.startswith("gain/"):
+            W[k[5:]] = T(g[k])
+    mel = torch.from_numpy(np.random.default_rng(L).uniform(-11.5, 2.0, (B, 80, L)).astype(np.float32))
+    ref = R.hifigan_forward(W, mel)
+    y = G(mel.cuda())
+    assert tuple(y.shape) == (B, 1, 256 * L)
+    assert_close(y.cpu(), ref, TOL, "hifigan B=%d L=%d" % (B, L))
+
+
+@pytest.mark.parametrize("K,dil,Ci,Co,L", [(3, 1, 64, 64, 333), (3, 5, 32, 32, 257), (7, 3, 128, 128, 400),
+                                           (11, 5, 32, 32, 129), (11, 1, 256, 256, 64), (7, 1, 32, 1, 515),
+                                           (7, 5, 64, 64, 9)])
+def test_dilated_conv_with_fused_activations(mg, K, dil, Ci, Co, L):
+    """mg_conv1d_fwd_ex: leaky_relu(x, in_slope) -> dilated conv -> *alpha + bias -> leaky_relu(act_slope) -> + add."""
+    gen = torch.Generator().manual_seed(K * 100 + dil)
+    x = torch.randn(2, Ci, L, generator=gen)
+    w = torch.randn(Co, Ci, K, generator=gen) / (Ci * K) ** 0.5
+    b = torch.randn(Co, generator=gen)
+    add = torch.randn(2, Co, L, generator=gen)
+    pad = (K * dil - dil) // 2
+    ref = F.leaky_relu(F.conv1d(F.leaky_relu(x, 0.1), w, None, 1, pad, dil) * 0.5 + b[None, :, None], 0.3) + add
+    wp = mg.ops.pack_conv_weight(w.cuda(), mg.ops.PACK_PLAIN)
+    y = mg.ops.conv1d_packed(x.cuda(), wp, b.cuda(), Co, K, 1, pad, act="lrelu_s", act_slope=0.3, alpha=0.5,
+                             add=add.cuda(), dilation=dil, in_slope=0.1)
+    assert_close(y.cpu(), ref, 1e-5, "dilated conv")
+
+
+@pytest.mark.parametrize("K,u,Ci,Co,L", [(16, 8, 512, 256, 13), (16, 8, 64, 32, 40), (4, 2, 128, 64, 77),
+                                         (4, 2, 64, 32, 1)])
+def test_conv_transpose_by_zero_insertion(mg, K, u, Ci, Co, L):
+    """ConvTranspose1d(k, stride u, padding (k-u)/2) of hifigan/models.py:121-127 == zero insertion + stride-1
+    conv with the transposed, tap-flipped weight."""
+    gen = torch.Generator().manual_seed(K + L)
+    x = torch.randn(2, Ci, L, generator=gen)
+    w = torch.randn(Ci, Co, K, generator=gen) / (Ci * K / u) ** 0.5
+    b = torch.randn(Co, generator=gen)
+    pad = (K - u) // 2
+    ref = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, u, pad)
+    wp = mg.ops.pack_conv_weight(w.cuda(), mg.ops.PACK_DGRAD)
+    z = mg.ops.upsample_zero(x.cuda(), u, (L - 1) * u + 1, slope=0.1)
+    y = mg.ops.conv1d_packed(z, wp, b.cuda(), Co, K, 1, K - 1 - pad, Lout=ref.shape[2])
+    assert_close(y.cpu(), ref, 1e-5, "conv transpose")
+
+
+def test_generator_cpu_input_fails_loudly(mg):
+    G = mg.vocoder.Generator(_h())
+    with pytest.raises(mg._lib.MixganHipError):
+        G(torch.zeros(1, 80, 4))

@@ -30,7 +30,7 @@ def test_error_strings_and_arg_checks():
     L = mg.lib()
     assert b"shape" in L.mg_error_string(-2)
     assert L.mg_conv_packed_floats(512, 256, 3, 1) == 16 * (256 * 3 // 8) * 256
-    assert L.mg_conv_packed_floats(512, 256, 4, 0) == 0          # unsupported kernel size
+    assert L.mg_conv_packed_floats(512, 256, 6, 0) == 0          # unsupported kernel size
     # null pointers are rejected before any launch (no GPU needed)
     assert L.mg_conv1d_fwd(None, None, None, None, None, None, 1, 8, 8, 8, 8, 1, 1, 0, 0, 1.0, 0, None) == -1
 

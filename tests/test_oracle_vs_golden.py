@@ -220,3 +220,17 @@ def test_lingops_index_functions():
     assert torch.equal(mm, T(g["mapping_mask"]))
     assert torch.equal(R.rel_coef(dur, swl, T(g["mel_mask"])), T(g["rel_coef_q"]))
     assert torch.equal(R.rel_coef(wb, swl, T(g["src_mask"])), T(g["rel_coef_kv"]))
+
+
+def test_hifigan_generator(manifest):
+    """hifigan/models.py:112-173 against a reference run (weight-norm gains from
+    the fixture, all other parameters from the seeded recipe)."""
+    g = golden("hifigan")
+    W, ck = seeded(manifest, "hifigan", 81)
+    np.testing.assert_allclose(ck, g["wsum"], rtol=1e-12)
+    for k in g:
+        if k.startswith("gain/"):
+            W[k[5:]] = T(g[k])
+    y = R.hifigan_forward(W, T(g["mel"]))
+    assert tuple(y.shape) == (2, 1, 13 * 256)
+    assert_close(y, g["wav"], 1e-5, "hifigan")

@@ -130,8 +130,40 @@ def lingops_bench():
                       "GBps": round(bytes_moved / t_ours / 1e9, 1)}), flush=True)
 
 
+def hifigan_flops(h, L):
+    """MACs*2 of one Generator.forward on L mel frames (hifigan/models.py:112-173)."""
+    c = h["upsample_initial_channel"]
+    fl = 2 * 80 * c * 7 * L
+    for i, (u, k) in enumerate(zip(h["upsample_rates"], h["upsample_kernel_sizes"])):
+        co = c // 2
+        L *= u
+        fl += 2 * c * co * (k // u) * L         # transposed conv: k/u live taps per output sample
+        for kk, ds in zip(h["resblock_kernel_sizes"], h["resblock_dilation_sizes"]):
+            fl += 2 * len(ds) * 2 * co * co * kk * L
+        c = co
+    return fl + 2 * c * 7 * L
+
+
+def vocoder_bench():
+    """HiFi-GAN V1 generator, B utterances of 1000 mel frames -> 256000 samples each."""
+    import types
+    from oracle import refmath as R
+    dev = torch.device("cuda", 0)
+    G = mg.vocoder.Generator(types.SimpleNamespace(**R.HIFIGAN_V1)).to(dev).eval()
+    G.remove_weight_norm()
+    for B, L in ((1, 1000), (16, 1000)):
+        mel = torch.empty(B, 80, L, device=dev).uniform_(-11.5, 2.0)
+        t = timeit(lambda: G(mel), 2, 5)
+        fl = hifigan_flops(R.HIFIGAN_V1, L) * B
+        print(json.dumps({"config": "f3 hifigan V1, B=%d, L=%d" % (B, L), "ms": round(t * 1e3, 2),
+                          "audio_seconds_per_s": round(B * L * 256 / 22050 / t, 1),
+                          "useful_TFLOPs": round(fl / t / 1e12, 1), "GFLOP": round(fl / 1e9, 1)}), flush=True)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "lingops":
         lingops_bench()
+    elif len(sys.argv) > 1 and sys.argv[1] == "vocoder":
+        vocoder_bench()
     else:
         main()

@@ -422,6 +422,27 @@ def main():
     arrs.update(mel_mask=mel_mask, src_mask=src_mask)
     save("lingops", **arrs)
 
+    # (f3) HiFi-GAN V1 generator (vocoder) -----------------------------------------------------------
+    print("hifigan")
+    import json as _json
+    from hifigan.models import Generator as HifiGenerator
+    with open(os.path.join(H.REF, "hifigan", "config.json")) as f:
+        hcfg = _json.load(f)
+    hobj = types.SimpleNamespace(**hcfg)
+    voc = HifiGenerator(hobj).eval()
+    ck = seed_module(voc, 81, "hifigan")
+    with torch.no_grad():   # keep the weight-norm gains near 1 so the 40-conv chain stays O(1)
+        for k_, p_ in voc.named_parameters():
+            if k_.endswith("weight_g"):
+                p_.copy_(1.0 + 0.1 * torch.from_numpy(rng.standard_normal(tuple(p_.shape)).astype(np.float32)))
+    gains = {k_: p_.detach().numpy().copy() for k_, p_ in voc.named_parameters() if k_.endswith("weight_g")}
+    melv = torch.from_numpy(rng.uniform(-11.5, 2.0, (2, 80, 13)).astype(np.float32))
+    with torch.no_grad():
+        wav = voc(melv)
+    arrs = dict(mel=melv, wav=wav, wsum=ck)
+    arrs.update({"gain/" + k_: v_ for k_, v_ in gains.items()})
+    save("hifigan", **arrs)
+
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(MANIFEST, f, indent=0, sort_keys=True)
     print("manifest written")
