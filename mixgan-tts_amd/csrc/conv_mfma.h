@@ -58,27 +58,64 @@ struct EpiBiasAct {
         const float *mask; // optional [B, Co, Lout] dense: result *= (mask > 0)   (ReLU backward)
         float act_slope;   // slope of MG_ACT_LRELU
     };
+    // Loads (residual add / ReLU mask / accumulate target) are issued for a whole 4-row group at clamped
+    // addresses before any of them is used, and only the store is predicated: a load inside a divergent
+    // `if (l < Lout)` makes hipcc fence every single one with s_waitcnt vmcnt(0).
     template <int WM, int NNB>
     static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][NNB], int b, int mrow0, int l0w,
                                                int lane, int Lout)
     {
         const int h = lane >> 5, c = lane & 31;
+        int lc[NNB];
+        bool lok[NNB];
+#pragma unroll
+        for (int j = 0; j < NNB; ++j) {
+            const int l = l0w + j * 32 + c;
+            lok[j] = l < Lout;
+            lc[j] = lok[j] ? l : Lout - 1;
+        }
+        const bool has_add = p.add != nullptr, has_mask = p.mask != nullptr, acc_out = p.accumulate != 0;
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mrow0 + i * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                if (row >= p.Co) continue;
-                const float bv = p.bias ? p.bias[row] : 0.f;
-                const size_t dense = ((size_t)b * p.Co + row) * Lout;
-                float *orow = p.out_bs ? p.out + (size_t)b * p.out_bs + (size_t)row * Lout : p.out + dense;
-                const float *arow = p.add ? p.add + dense : nullptr;
-                const float *mrow = p.mask ? p.mask + dense : nullptr;
+            for (int rq = 0; rq < 4; ++rq) {
+                const int row0 = mrow0 + i * 32 + 8 * rq + 4 * h;
+                if (row0 >= p.Co) continue;   // Co is a multiple of 4 or the tail rows are clamped below
+                float av[4][NNB], mv[4][NNB], ov[4][NNB], bv[4];
+                size_t dense[4], orow[4];
+                bool rok[4];
 #pragma unroll
-                for (int j = 0; j < NNB; ++j) {
-                    const int l = l0w + j * 32 + c;
-                    if (l < Lout) {
-                        float v = acc[i][j][r] * p.alpha + bv;
+                for (int e = 0; e < 4; ++e) {
+                    const int row = row0 + e;
+                    rok[e] = row < p.Co;
+                    const int rc = rok[e] ? row : p.Co - 1;
+                    dense[e] = ((size_t)b * p.Co + rc) * Lout;
+                    orow[e] = p.out_bs ? (size_t)b * p.out_bs + (size_t)rc * Lout : dense[e];
+                    bv[e] = p.bias ? p.bias[rc] : 0.f;
+                }
+                if (has_add) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int j = 0; j < NNB; ++j) av[e][j] = p.add[dense[e] + lc[j]];
+                }
+                if (has_mask) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int j = 0; j < NNB; ++j) mv[e][j] = p.mask[dense[e] + lc[j]];
+                }
+                if (acc_out) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int j = 0; j < NNB; ++j) ov[e][j] = p.out[orow[e] + lc[j]];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int j = 0; j < NNB; ++j) {
+                        float v = acc[i][j][rq * 4 + e] * p.alpha + bv[e];
                         switch (p.act) {
                         case MG_ACT_RELU: v = mg_act<MG_ACT_RELU>(v); break;
                         case MG_ACT_LRELU02: v = mg_act<MG_ACT_LRELU02>(v); break;
@@ -86,10 +123,10 @@ struct EpiBiasAct {
                         case MG_ACT_LRELU: v = v > 0.f ? v : p.act_slope * v; break;
                         default: break;
                         }
-                        if (arow) v += arow[l];
-                        if (mrow) v = mrow[l] > 0.f ? v : 0.f;
-                        if (p.accumulate) v += orow[l];
-                        orow[l] = v;
+                        if (has_add) v += av[e][j];
+                        if (has_mask) v = mv[e][j] > 0.f ? v : 0.f;
+                        if (acc_out) v += ov[e][j];
+                        if (rok[e] && lok[j]) p.out[orow[e] + lc[j]] = v;
                     }
                 }
             }
@@ -140,70 +177,104 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, typename 
     const float *inb = a.in + (size_t)b * a.in_bs;
     const int lbase = l0 * STRIDE - a.pad;
 
-    float stage[NLD];
-    auto load_stage = [&](int chunk) {
+    // Register-staged prefetch of one [CK x TW] input slab.  All NLD loads of a chunk are issued
+    // back to back at clamped (always valid) addresses; out-of-range samples are zeroed, and the
+    // optional per-channel vector / leaky ReLU applied, only when the registers go to LDS after the
+    // MFMAs of the previous chunk -- so the loads fly behind the whole chunk of matrix work.
+    float stage[NLD], svec[NLD];
+    int lcl[NLD];           // clamped input frame of element k (chunk-invariant)
+    unsigned lmask = 0;     // bit k: element k is inside the tile and its frame inside [0, Lin)
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int idx = tid + k * 256;
+        const int row = idx / TW;
+        const int l = lbase + (idx - row * TW);
+        if (idx < TILE && l >= 0 && l < a.Lin) lmask |= 1u << k;
+        lcl[k] = l < 0 ? 0 : (l >= a.Lin ? a.Lin - 1 : l);
+    }
+    const bool has_vec = a.in_vec != nullptr;
+    const float *vecb = has_vec ? a.in_vec + (size_t)b * a.Ci : nullptr;
+    // element k of the slab of `chunk`: one clamped global load (+ the per-channel vector)
+    auto load_elem = [&](int chunk, int k) {
+        const int ci = chunk * CK + (tid + k * 256) / TW;
+        const int cic = ci < a.Ci ? ci : a.Ci - 1;
+        stage[k] = inb[(size_t)cic * a.in_rs + lcl[k]];
+        if (has_vec) svec[k] = vecb[cic];
+    };
+    auto store_stage = [&](int buf, int chunk) {
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
             const int idx = tid + k * 256;
-            const int row = idx / TW;
-            const int col = idx - row * TW;
-            const int ci = chunk * CK + row;
-            const int l = lbase + col;
-            float v = 0.f;
-            if (idx < TILE && ci < a.Ci && l >= 0 && l < a.Lin) {
-                v = inb[(size_t)ci * a.in_rs + l];
-                if (a.in_vec) v += a.in_vec[(size_t)b * a.Ci + ci];
-                v = v > 0.f ? v : v * a.in_slope;
-            }
-            stage[k] = v;
-        }
-    };
-    auto store_stage = [&](int buf) {
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int idx = tid + k * 256;
-            if (idx < TILE) lds[buf][idx] = stage[k];
+            const int ci = chunk * CK + idx / TW;
+            float v = stage[k];
+            if (has_vec) v += svec[k];
+            v = v > 0.f ? v : v * a.in_slope;
+            v = ((lmask >> k) & 1u) && ci < a.Ci ? v : 0.f;
+            if (idx < TILE) lds[buf][idx] = v;
         }
     };
 
-    f32x4 a_cur[WM], a_nxt[WM];
+    // Operand pipeline (all indices static, pinned with sched_barrier so hipcc cannot sink the
+    // prefetches next to their use): weights AD k-groups ahead in a shifting register queue, the B
+    // fragments of the next k-group read from LDS while the 4*WM*NNB MFMAs of the current one issue,
+    // and the NLD slab loads of the next chunk spread evenly over this chunk's k-groups -- vmcnt
+    // retires in order, so a burst of HBM-latency slab loads in front of the L2-latency weight loads
+    // would stall the weight queue.
+    constexpr int AD = 3;
+    f32x4 aq[AD + 1][WM];
 #pragma unroll
-    for (int i = 0; i < WM; ++i) a_cur[i] = ap[i][0];
+    for (int d = 0; d < AD; ++d)
+#pragma unroll
+        for (int i = 0; i < WM; ++i) aq[d][i] = ap[i][(size_t)(d < Q ? d : Q - 1) * 64];
 
-    load_stage(0);
-    store_stage(0);
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) load_elem(0, k);
+    store_stage(0, 0);
     __syncthreads();
 
     int q = 0;
     const int boff = (wn * 32 * NNB + c32) * STRIDE + h * TW;
+    auto read_b = [&](const float *L, int gi, float (&bv)[4][NNB]) {
+        const int tap = gi / (CK / 8), g = gi % (CK / 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < NNB; ++j)
+                bv[e][j] = L[boff + (2 * (g * 4 + e)) * TW + (DILMAX > 1 ? tap * a.dil : tap) + 32 * j * STRIDE];
+    };
     for (int ch = 0; ch < nchunks; ++ch) {
-        if (ch + 1 < nchunks) load_stage(ch + 1);
         const float *L = lds[ch & 1];
+        const int chn = ch + 1 < nchunks ? ch + 1 : ch;   // last chunk: harmless reload of itself
+        float bc[4][NNB], bn[4][NNB];
+        read_b(L, 0, bc);
 #pragma unroll
-        for (int tap = 0; tap < KW; ++tap) {
+        for (int gi = 0; gi < QC; ++gi) {
+            const int qn = q + AD < Q ? q + AD : Q - 1;
 #pragma unroll
-            for (int g = 0; g < CK / 8; ++g) {
-                ++q;
-                const int qn = q < Q ? q : Q - 1;
+            for (int i = 0; i < WM; ++i) aq[AD][i] = ap[i][(size_t)qn * 64];
 #pragma unroll
-                for (int i = 0; i < WM; ++i) a_nxt[i] = ap[i][(size_t)qn * 64];
+            for (int k = gi * NLD / QC; k < (gi + 1) * NLD / QC; ++k) load_elem(chn, k);
+            if (gi + 1 < QC) read_b(L, gi + 1, bn);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int s = g * 4 + e;
-                    float bv[NNB];
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int j = 0; j < NNB; ++j) bv[j] = L[boff + (2 * s) * TW + (DILMAX > 1 ? tap * a.dil : tap) + 32 * j * STRIDE];
+                for (int i = 0; i < WM; ++i)
 #pragma unroll
-                    for (int i = 0; i < WM; ++i)
+                    for (int j = 0; j < NNB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[0][i][e], bc[e][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int j = 0; j < NNB; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i][e], bv[j], acc[i][j], 0, 0, 0);
-                }
+            for (int d = 0; d < AD; ++d)
 #pragma unroll
-                for (int i = 0; i < WM; ++i) a_cur[i] = a_nxt[i];
-            }
+                for (int i = 0; i < WM; ++i) aq[d][i] = aq[d + 1][i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < NNB; ++j) bc[e][j] = bn[e][j];
+            ++q;
         }
-        if (ch + 1 < nchunks) store_stage((ch + 1) & 1);
+        if (ch + 1 < nchunks) store_stage((ch + 1) & 1, ch + 1);
         __syncthreads();
     }
 

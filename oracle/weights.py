@@ -1,4 +1,4 @@
-"""Replayable weight recipe shared by tools/make_golden.py (reference side) and the tests.
+"""Replayable weight recipe shared by tests/golden/make_golden.py (reference side) and the tests.
 
 The reference ships no checkpoints, so parity fixtures use seeded random
 weights.  To keep the fixtures small the weights themselves are never committed: both sides

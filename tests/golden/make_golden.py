@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz by running the REAL reference (/root/reference) on CPU.
 
-Run in the build container only:   python tools/make_golden.py
+Run in the build container only:   python tests/golden/make_golden.py
 The reference source never leaves this container; only inputs/outputs (data) are written.
 Weights are not stored: they are re-drawn on both sides by oracle/weights.py from the
 state_dict manifest kept in tests/golden/manifest.json.
@@ -17,7 +17,7 @@ import types
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ROOT = os.path.dirname(HERE)
+ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
 

@@ -1,6 +1,6 @@
 """Import harness for the read-only reference at /root/reference (THIS CONTAINER ONLY).
 
-Used only by tools/make_golden.py to generate the committed fixtures under tests/golden/.
+Used only by tests/golden/make_golden.py to generate the committed fixtures under tests/golden/.
 Nothing under tests/, bench.py or the package imports this file: /root/reference does not
 exist on the GPU box.
 

@@ -22,7 +22,7 @@ def T(a):
 
 
 def seeded(manifest, name, seed, prefix="", requires_grad=False):
-    """Draw the weights of fixture module `name` exactly as tools/make_golden.py did."""
+    """Draw the weights of fixture module `name` exactly as tests/golden/make_golden.py did."""
     w = WR.draw(manifest[name]["seeded"], seed)
     out = {}
     for k, a in w.items():

@@ -7,7 +7,7 @@ import sys
 import tempfile
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # tests/ -> repo root
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -160,8 +160,51 @@ def vocoder_bench():
                           "useful_TFLOPs": round(fl / t / 1e12, 1), "GFLOP": round(fl / 1e9, 1)}), flush=True)
 
 
+def stock_eager_bench():
+    """Second baseline of SURVEY.md section 8(d): the reference's op sequence as stock PyTorch-ROCm eager
+    (MIOpen / rocBLAS; oracle/refmath.py moved to the GPU) on the same card, same shapes as the bench line,
+    next to our HIP path.  fp32, TF32-style downcasts off (torch default)."""
+    import types
+    from oracle import refmath as R
+    dev = torch.device("cuda", 0)
+    d = tempfile.mkdtemp()
+    stats = write_stats(d, [-11.5] * 80, [2.0] * 80, n_speakers=218)
+    B, L = 16, 1000
+    gd = mg.GaussianDiffusion(*hot_path_configs("naive", 4, stats_dir=stats))
+    seeded_(gd, 1)
+    gd = gd.to(dev).eval()
+    W = {k: v.detach() for k, v in gd.state_dict().items()}
+    buf = {k: v.detach() for k, v in gd._buf().items()}
+    x = torch.randn(B, 1, 80, L, device=dev)
+    cond = torch.randn(B, 256, L, device=dev)
+    t = torch.full((B,), 3, dtype=torch.long, device=dev)
+    nz = torch.randn(B, 1, 80, L, device=dev)
+    with torch.no_grad():
+        ref = R.p_sample(W, buf, x, t, cond, None, nz)
+        gd.noise_fn = lambda shape: nz
+        ours = gd.p_sample(x, t, cond, None)
+        gd.noise_fn = None
+        ts = timeit(lambda: R.p_sample(W, buf, x, t, cond, None, nz), 3, 20)
+        to = timeit(lambda: gd.p_sample(x, t, cond, None), 3, 20)
+    print(json.dumps({"config": "cfg2 p_sample step B=16 L=1000", "stock_pytorch_rocm_eager_ms": round(ts * 1e3, 3),
+                      "ours_ms": round(to * 1e3, 3), "speedup": round(ts / to, 2),
+                      "max_abs_diff_same_noise": float((ours - ref).abs().max())}), flush=True)
+    G = mg.vocoder.Generator(types.SimpleNamespace(**R.HIFIGAN_V1)).to(dev).eval()
+    Wv = {k: v.detach() for k, v in G.state_dict().items()}
+    for Bv in (1, 16):
+        mel = torch.empty(Bv, 80, L, device=dev).uniform_(-11.5, 2.0)
+        with torch.no_grad():
+            err = float((G(mel) - R.hifigan_forward(Wv, mel)).abs().max())
+            ts = timeit(lambda: R.hifigan_forward(Wv, mel), 1, 3)
+        to = timeit(lambda: G(mel), 1, 3)
+        print(json.dumps({"config": "hifigan V1 B=%d L=1000" % Bv, "stock_pytorch_rocm_eager_ms": round(ts * 1e3, 2),
+                          "ours_ms": round(to * 1e3, 2), "speedup": round(ts / to, 2), "max_abs_diff": err}), flush=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "lingops":
+    if len(sys.argv) > 1 and sys.argv[1] == "stock":
+        stock_eager_bench()
+    elif len(sys.argv) > 1 and sys.argv[1] == "lingops":
         lingops_bench()
     elif len(sys.argv) > 1 and sys.argv[1] == "vocoder":
         vocoder_bench()

@@ -1,5 +1,5 @@
 """Pins oracle/ (the CPU restatement) to outputs of the REAL reference (tests/golden/*.npz,
-made by tools/make_golden.py from /root/reference).  CPU only; tolerance 2e-6 relative for
+made by tests/golden/make_golden.py from /root/reference).  CPU only; tolerance 2e-6 relative for
 fp32 forwards (same ATen ops, different association in a few places), 2e-5 for gradients.
 """
 import numpy as np
