@@ -53,6 +53,7 @@ const char *mg_error_string(int code);
 #define MG_PACK_PLAIN 0  /* rows in natural order */
 #define MG_PACK_GATE 1   /* rows interleaved so that channel c and c+Co/2 share a lane (GLU gate) */
 #define MG_PACK_DGRAD 2  /* transposed + tap-flipped: the data-gradient convolution (stride 1) */
+#define MG_PACK_TPOSE 3  /* internal to mg_conv_transpose_pack (polyphase ConvTranspose1d); rejected by mg_conv_pack */
 
 /* Number of floats of the packed form of a [Co, Ci, K] weight. */
 size_t mg_conv_packed_floats(int Co, int Ci, int K, int mode);
@@ -214,6 +215,15 @@ int mg_upsample_zero(const float *in, float *out, int rows, int Lin, int stride,
  * zero insertion followed by a stride-1 convolution on the MG_PACK_DGRAD pack of the [Cin, Cout, K] weight. */
 int mg_upsample_zero_act(const float *in, float *out, int rows, int Lin, int stride, int Lup, float slope,
                          void *stream);
+/* ConvTranspose1d(Ci, Co, kernel 2u, stride u, padding u/2) of hifigan/models.py:121-127,151 without the zeros:
+ * output phase r = n mod u is a 2-tap convolution of the input, so all u phases together are one 3-tap
+ * implicit GEMM with Co*u rows (3/2 of the useful MACs instead of u times them with zero insertion) whose
+ * epilogue interleaves the phases back into out [B, Co, u*Lin] with 16-byte stores.  u in {2,4,8}.
+ * w is the PyTorch ConvTranspose1d weight [Ci, Co, 2u]; out = alpha * convT(lrelu(in, in_slope)) + bias. */
+size_t mg_conv_transpose_packed_floats(int Ci, int Co, int u);
+int mg_conv_transpose_pack(const float *w, float *packed, int Ci, int Co, int u, void *stream);
+int mg_conv_transpose1d_fwd(const float *in, const float *packed, const float *bias, float *out, int B, int Ci,
+                            int Lin, int Co, int u, float in_slope, float alpha, void *stream);
 
 /* Step-embedding MLP: out = W2 mish(W0 [sin|cos](t * freq)).  Denoiser: model/modules.py:398-403,434;
  * JCUDiscriminator: model/mixgantts.py:203-208,265.  emb [B,D0], pre/h [B,D1] are saved for backward. */

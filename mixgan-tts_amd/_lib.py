@@ -11,7 +11,7 @@ _LIB = None
 EXPORTS = (
     "mg_version", "mg_error_string",
     "mg_conv_packed_floats", "mg_conv_pack", "mg_conv_pack_at", "mg_conv1d_fwd", "mg_conv1d_fwd_ex",
-    "mg_upsample_zero_act",
+    "mg_upsample_zero_act", "mg_conv_transpose_packed_floats", "mg_conv_transpose_pack", "mg_conv_transpose1d_fwd",
     "mg_conv1d_wgrad_scratch_floats", "mg_conv1d_wgrad", "mg_conv1d_wgrad_strided", "mg_rowsum",
     "mg_diffuse_fwd", "mg_posterior_sample_fwd", "mg_posterior_sample_bwd", "mg_spec_affine", "mg_transpose_bml",
     "mg_denoiser_packed_floats", "mg_denoiser_pack", "mg_denoiser_workspace_floats", "mg_denoiser_fwd",
@@ -72,6 +72,9 @@ def _declare(L):
         "mg_conv1d_fwd": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, f, i, vp]),
         "mg_conv1d_fwd_ex": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, f, i, f, f, i, vp]),
         "mg_upsample_zero_act": (i, [vp, vp, i, i, i, i, f, vp]),
+        "mg_conv_transpose_packed_floats": (sz, [i, i, i]),
+        "mg_conv_transpose_pack": (i, [vp, vp, i, i, i, vp]),
+        "mg_conv_transpose1d_fwd": (i, [vp, vp, vp, vp, i, i, i, i, i, f, f, vp]),
         "mg_diffuse_fwd": (i, [vp] * 9 + [i, i, i, i, vp]),
         "mg_posterior_sample_fwd": (i, [vp] * 10 + [i, i, i, i, i, vp]),
         "mg_transpose_bml": (i, [vp] * 5 + [i, i, i, i, i, vp]),

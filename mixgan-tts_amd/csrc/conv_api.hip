@@ -6,7 +6,7 @@
 // pack: [Co, Ci, K] fp32 -> Wp[mb][q][lane][e]  (layout: conv_mfma.h header)
 // ---------------------------------------------------------------------------------------------
 __global__ void pack_conv_kernel(const float *__restrict__ w, float *__restrict__ wp, int Co, int Ci, int K, int CK,
-                                 int CiP, int MB, int mode, int q0, int Qtot)
+                                 int CiP, int MB, int mode, int q0, int Qtot, int u)
 {
     const int Q = CiP * K / 8;
     const size_t total = (size_t)MB * Q * 256;
@@ -30,6 +30,17 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, float *__restrict_
         } else if (mode == MG_PACK_GATE) {
             const int half = mb & 1, rr = (mb >> 1) * 32 + r;
             if (rr < Co / 2 && ci < Ci) v = w[((size_t)(half * (Co / 2) + rr) * Ci + ci) * K + tap];
+        } else if (mode == MG_PACK_TPOSE) {
+            // ConvTranspose1d weight [Ci, Co', 2u] (stride u, padding u/2) as the 3-tap polyphase GEMM:
+            // row = co*u + phase; output u*m + phase reads x[m + c0] with tap rho and x[m + c0 - 1] with
+            // tap rho + u, where rho = (phase + u/2) % u, c0 = (phase + u/2) / u; here `Co` = Co' * u.
+            const int row = mb * 32 + r;
+            if (row < Co && ci < Ci) {
+                const int co = row / u, ph = row - co * u;
+                const int rho = (ph + u / 2) % u, c0 = (ph + u / 2) / u;
+                const int t = tap == c0 + 1 ? rho : (tap == c0 ? rho + u : -1);
+                if (t >= 0) v = w[((size_t)ci * (Co / u) + co) * (2 * u) + t];
+            }
         } else {  // MG_PACK_DGRAD: rows = source Ci, reduction = source Co, taps flipped
             const int row = mb * 32 + r;
             if (row < Ci && ci < Co) v = w[((size_t)ci * Ci + row) * K + (K - 1 - tap)];
@@ -84,7 +95,7 @@ extern "C" int mg_conv_pack_at(const float *w, float *packed, int Co, int Ci, in
     const size_t total = (size_t)MB * Q * 256;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_conv_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Co, Ci, K, CK, CiP,
-                       MB, mode, q0, Qtot);
+                       MB, mode, q0, Qtot, 0);
     MG_LAUNCH_CHECK();
     return MG_OK;
 }
@@ -97,8 +108,41 @@ extern "C" int mg_conv_pack(const float *w, float *packed, int Co, int Ci, int K
     return mg_conv_pack_at(w, packed, Co, Ci, K, mode, 0, Q, stream);
 }
 
+// ConvTranspose1d(Ci -> Co, kernel 2u, stride u, padding u/2) -- hifigan/models.py:121-127 -- as a polyphase
+// GEMM: no zero insertion, 3 taps instead of 2u on the matrix cores.
+static bool tpose_ok(int Ci, int Co, int u) { return Ci > 0 && Co > 0 && (u == 2 || u == 4 || u == 8) && (Co * u) % 4 == 0; }
+
+extern "C" size_t mg_conv_transpose_packed_floats(int Ci, int Co, int u)
+{
+    if (!tpose_ok(Ci, Co, u)) return 0;
+    return (size_t)mg_conv_mblocks(Co * u) * (mg_round_up(Ci, mg_conv_ck(3)) * 3 / 8) * 256;
+}
+
+extern "C" int mg_conv_transpose_pack(const float *w, float *packed, int Ci, int Co, int u, void *stream)
+{
+    if (!w || !packed) return MG_ERR_ARG;
+    if (!tpose_ok(Ci, Co, u)) return MG_ERR_SHAPE;
+    const int CK = mg_conv_ck(3), CiP = mg_round_up(Ci, CK), MB = mg_conv_mblocks(Co * u), Q = CiP * 3 / 8;
+    const size_t total = (size_t)MB * Q * 256;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_conv_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Co * u, Ci, 3, CK,
+                       CiP, MB, MG_PACK_TPOSE, 0, Q, u);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
+}
+
 template <>
 struct EpiWide<EpiBiasAct> { static constexpr bool value = true; };
+
+extern "C" int mg_conv_transpose1d_fwd(const float *in, const float *packed, const float *bias, float *out, int B, int Ci,
+                                       int Lin, int Co, int u, float in_slope, float alpha, void *stream)
+{
+    if (!in || !packed || !out) return MG_ERR_ARG;
+    if (B <= 0 || Lin <= 0 || !tpose_ok(Ci, Co, u)) return MG_ERR_SHAPE;
+    ConvShape s{B, Ci, Lin, Lin, 3, 1, 1, Co * u, 0, 0, 1, in_slope};
+    EpiBiasAct::Params ep{out, bias, nullptr, alpha, Co, MG_ACT_NONE, 0, 0, nullptr, 0.f, u};
+    return conv_launch<EpiBiasAct>(s, in, nullptr, packed, ep, (hipStream_t)stream);
+}
 
 extern "C" int mg_conv1d_fwd_ex(const float *in, const float *in_vec, const float *packed, const float *bias,
                                 const float *add, float *out, int B, int Ci, int Lin, int Co, int Lout, int K,

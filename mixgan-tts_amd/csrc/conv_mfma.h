@@ -57,15 +57,21 @@ struct EpiBiasAct {
         long out_bs;       // batch stride of out (0 -> Co*Lout): lets the output be a channel slice
         const float *mask; // optional [B, Co, Lout] dense: result *= (mask > 0)   (ReLU backward)
         float act_slope;   // slope of MG_ACT_LRELU
+        int phase_u;       // > 0: polyphase transposed conv, rows = Co * phase_u (see run_phases)
     };
-    // Loads (residual add / ReLU mask / accumulate target) are issued for a whole 4-row group at clamped
+    // Loads (residual add / ReLU mask / accumulate target) of a whole 32-row block are issued at clamped
     // addresses before any of them is used, and only the store is predicated: a load inside a divergent
-    // `if (l < Lout)` makes hipcc fence every single one with s_waitcnt vmcnt(0).
+    // `if (l < Lout)` makes hipcc fence every single one with s_waitcnt vmcnt(0), i.e. 16*WM*NNB serial
+    // HBM round trips per wave.
     template <int WM, int NNB>
     static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][NNB], int b, int mrow0, int l0w,
                                                int lane, int Lout)
     {
         const int h = lane >> 5, c = lane & 31;
+        if (p.phase_u > 0) {
+            run_phases<WM, NNB>(p, acc, b, mrow0, l0w, lane, Lout);
+            return;
+        }
         int lc[NNB];
         bool lok[NNB];
 #pragma unroll
@@ -77,45 +83,45 @@ struct EpiBiasAct {
         const bool has_add = p.add != nullptr, has_mask = p.mask != nullptr, acc_out = p.accumulate != 0;
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
+            if (mrow0 + i * 32 >= p.Co) continue;   // wave-uniform
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int row0 = mrow0 + i * 32 + 8 * rq + 4 * h;
-                if (row0 >= p.Co) continue;   // Co is a multiple of 4 or the tail rows are clamped below
-                float av[4][NNB], mv[4][NNB], ov[4][NNB], bv[4];
-                size_t dense[4], orow[4];
-                bool rok[4];
+            for (int half = 0; half < 2; ++half) {   // 8 rows x NNB frames per batch of loads
+                float av[8][NNB], mv[8][NNB], ov[8][NNB], bv[8];
+                size_t dense[8], orow[8];
+                bool rok[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int row = row0 + e;
-                    rok[e] = row < p.Co;
-                    const int rc = rok[e] ? row : p.Co - 1;
-                    dense[e] = ((size_t)b * p.Co + rc) * Lout;
-                    orow[e] = p.out_bs ? (size_t)b * p.out_bs + (size_t)rc * Lout : dense[e];
-                    bv[e] = p.bias ? p.bias[rc] : 0.f;
+                for (int r = 0; r < 8; ++r) {
+                    const int rr = half * 8 + r;
+                    const int row = mrow0 + i * 32 + 8 * (rr >> 2) + 4 * h + (rr & 3);
+                    rok[r] = row < p.Co;
+                    const int rc = rok[r] ? row : p.Co - 1;
+                    dense[r] = ((size_t)b * p.Co + rc) * Lout;
+                    orow[r] = p.out_bs ? (size_t)b * p.out_bs + (size_t)rc * Lout : dense[r];
+                    bv[r] = p.bias ? p.bias[rc] : 0.f;
                 }
                 if (has_add) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                    for (int r = 0; r < 8; ++r)
 #pragma unroll
-                        for (int j = 0; j < NNB; ++j) av[e][j] = p.add[dense[e] + lc[j]];
+                        for (int j = 0; j < NNB; ++j) av[r][j] = p.add[dense[r] + lc[j]];
                 }
                 if (has_mask) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                    for (int r = 0; r < 8; ++r)
 #pragma unroll
-                        for (int j = 0; j < NNB; ++j) mv[e][j] = p.mask[dense[e] + lc[j]];
+                        for (int j = 0; j < NNB; ++j) mv[r][j] = p.mask[dense[r] + lc[j]];
                 }
                 if (acc_out) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                    for (int r = 0; r < 8; ++r)
 #pragma unroll
-                        for (int j = 0; j < NNB; ++j) ov[e][j] = p.out[orow[e] + lc[j]];
+                        for (int j = 0; j < NNB; ++j) ov[r][j] = p.out[orow[r] + lc[j]];
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int r = 0; r < 8; ++r) {
 #pragma unroll
                     for (int j = 0; j < NNB; ++j) {
-                        float v = acc[i][j][rq * 4 + e] * p.alpha + bv[e];
+                        float v = acc[i][j][half * 8 + r] * p.alpha + bv[r];
                         switch (p.act) {
                         case MG_ACT_RELU: v = mg_act<MG_ACT_RELU>(v); break;
                         case MG_ACT_LRELU02: v = mg_act<MG_ACT_LRELU02>(v); break;
@@ -123,10 +129,54 @@ struct EpiBiasAct {
                         case MG_ACT_LRELU: v = v > 0.f ? v : p.act_slope * v; break;
                         default: break;
                         }
-                        if (has_add) v += av[e][j];
-                        if (has_mask) v = mv[e][j] > 0.f ? v : 0.f;
-                        if (acc_out) v += ov[e][j];
-                        if (rok[e] && lok[j]) p.out[orow[e] + lc[j]] = v;
+                        if (has_add) v += av[r][j];
+                        if (has_mask) v = mv[r][j] > 0.f ? v : 0.f;
+                        if (acc_out) v += ov[r][j];
+                        if (rok[r] && lok[j]) p.out[orow[r] + lc[j]] = v;
+                    }
+                }
+            }
+        }
+    }
+
+    // Polyphase transposed convolution (mg_conv_transpose1d_fwd): GEMM row = co*u + r is phase r of
+    // output channel co, GEMM column m is the input frame; element -> out[b, co, u*m + r].  The 4
+    // consecutive rows a lane holds are 4 consecutive phases (u >= 4: one 16-byte store; the 2 x 32
+    // lanes of a wave then write one contiguous run per channel) or 2 phases of 2 channels (u = 2).
+    template <int WM, int NNB>
+    static __device__ __forceinline__ void run_phases(const Params &p, f32x16 (&acc)[WM][NNB], int b, int mrow0,
+                                                      int l0w, int lane, int Lm)
+    {
+        const int h = lane >> 5, c = lane & 31, u = p.phase_u;
+        const int Mrows = p.Co * u;
+        const size_t Lfull = (size_t)Lm * u;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int row0 = mrow0 + i * 32 + 8 * rq + 4 * h;
+                if (row0 >= Mrows) continue;
+#pragma unroll
+                for (int j = 0; j < NNB; ++j) {
+                    const int m = l0w + j * 32 + c;
+                    if (m >= Lm) continue;
+                    if (u >= 4) {
+                        const int co = row0 / u, r0 = row0 - co * u;
+                        const float bv = p.bias ? p.bias[co] : 0.f;
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][rq * 4 + e] * p.alpha + bv;
+                        *reinterpret_cast<f32x4 *>(p.out + ((size_t)b * p.Co + co) * Lfull + (size_t)m * u + r0) = v;
+                    } else {   // u == 2
+#pragma unroll
+                        for (int e2 = 0; e2 < 2; ++e2) {
+                            const int co = (row0 >> 1) + e2;
+                            const float bv = p.bias ? p.bias[co] : 0.f;
+                            float2 v;
+                            v.x = acc[i][j][rq * 4 + 2 * e2] * p.alpha + bv;
+                            v.y = acc[i][j][rq * 4 + 2 * e2 + 1] * p.alpha + bv;
+                            *reinterpret_cast<float2 *>(p.out + ((size_t)b * p.Co + co) * Lfull + (size_t)m * 2) = v;
+                        }
                     }
                 }
             }
@@ -135,13 +185,16 @@ struct EpiBiasAct {
 };
 
 // ---------------------------------------------------------------------------------------------
-template <int KW, int STRIDE, int CK, int DILMAX, int WM, int NNB, class Epi>
+template <int KW, int STRIDE, int CK, int DILMAX, int MW, int WM, int NNB, class Epi>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, typename Epi::Params ep)
 {
-    constexpr int NT = 64 * NNB;  // output frames per workgroup: 2 (N) waves x NNB 32-frame blocks
+    static_assert(MW == 2 || (MW == 1 && WM == 1), "wave layouts: 2(M) x 2(N), or 1 x 4 for <= 32 output rows");
+    constexpr int NW = 4 / MW;         // waves along the frame axis
+    constexpr int NT = NW * 32 * NNB;  // output frames per workgroup
     constexpr int TW = NT * STRIDE + (KW - 1) * DILMAX;  // input frames per tile row (taps at multiples of a.dil)
     constexpr int TILE = CK * TW;
     constexpr int NLD = (TILE + 255) / 256;
+    static_assert(NLD <= 64, "slab too large for the validity bit mask");
     constexpr int QC = KW * (CK / 8);  // k-groups per chunk
 
     __shared__ float lds[2][TILE];
@@ -149,14 +202,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, typename 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = MW == 2 ? wave >> 1 : 0, wn = MW == 2 ? wave & 1 : wave;
     const int h = lane >> 5, c32 = lane & 31;
 
     const int nt = blockIdx.x % a.ntiles_total;
     const int mt = blockIdx.x / a.ntiles_total;
     const int b = nt / a.ntiles_per_b;
     const int l0 = (nt % a.ntiles_per_b) * NT;
-    const int mb0 = mt * (2 * WM) + wm * WM;  // first 32-row block of this wave
+    const int mb0 = mt * (MW * WM) + wm * WM;  // first 32-row block of this wave
 
     const int nchunks = a.CiP / CK;
     const int Q = nchunks * QC;
@@ -182,23 +235,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, typename 
     // optional per-channel vector / leaky ReLU applied, only when the registers go to LDS after the
     // MFMAs of the previous chunk -- so the loads fly behind the whole chunk of matrix work.
     float stage[NLD], svec[NLD];
-    int lcl[NLD];           // clamped input frame of element k (chunk-invariant)
-    unsigned lmask = 0;     // bit k: element k is inside the tile and its frame inside [0, Lin)
+    unsigned long long lmask = 0;  // bit k: element k is inside the tile and its frame inside [0, Lin)
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
         const int idx = tid + k * 256;
         const int row = idx / TW;
         const int l = lbase + (idx - row * TW);
-        if (idx < TILE && l >= 0 && l < a.Lin) lmask |= 1u << k;
-        lcl[k] = l < 0 ? 0 : (l >= a.Lin ? a.Lin - 1 : l);
+        if (idx < TILE && l >= 0 && l < a.Lin) lmask |= 1ull << k;
     }
     const bool has_vec = a.in_vec != nullptr;
     const float *vecb = has_vec ? a.in_vec + (size_t)b * a.Ci : nullptr;
     // element k of the slab of `chunk`: one clamped global load (+ the per-channel vector)
     auto load_elem = [&](int chunk, int k) {
-        const int ci = chunk * CK + (tid + k * 256) / TW;
+        const int idx = tid + k * 256, row = idx / TW;
+        const int ci = chunk * CK + row, l = lbase + (idx - row * TW);
         const int cic = ci < a.Ci ? ci : a.Ci - 1;
-        stage[k] = inb[(size_t)cic * a.in_rs + lcl[k]];
+        const int lcl = l < 0 ? 0 : (l >= a.Lin ? a.Lin - 1 : l);   // clamped: always a valid address
+        stage[k] = inb[(size_t)cic * a.in_rs + lcl];
         if (has_vec) svec[k] = vecb[cic];
     };
     auto store_stage = [&](int buf, int chunk) {
@@ -209,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, typename 
             float v = stage[k];
             if (has_vec) v += svec[k];
             v = v > 0.f ? v : v * a.in_slope;
-            v = ((lmask >> k) & 1u) && ci < a.Ci ? v : 0.f;
+            v = ((lmask >> k) & 1ull) && ci < a.Ci ? v : 0.f;
             if (idx < TILE) lds[buf][idx] = v;
         }
     };
@@ -278,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, typename 
         __syncthreads();
     }
 
-    Epi::template run<WM, NNB>(ep, acc, b, (mt * 2 + wm) * (32 * WM), l0 + wn * 32 * NNB, lane, a.Lout);
+    Epi::template run<WM, NNB>(ep, acc, b, (mt * MW + wm) * (32 * WM), l0 + wn * 32 * NNB, lane, a.Lout);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -292,7 +345,7 @@ struct ConvShape {
     float in_slope = 1.f;
 };
 
-template <int KW, int STRIDE, int CK, int DILMAX, int WM, int NNB, class Epi>
+template <int KW, int STRIDE, int CK, int DILMAX, int MW, int WM, int NNB, class Epi>
 static int conv_launch_t(const ConvShape &s, const float *in, const float *in_vec, const float *wp,
                          const typename Epi::Params &ep, hipStream_t st)
 {
@@ -310,11 +363,11 @@ static int conv_launch_t(const ConvShape &s, const float *in, const float *in_ve
     a.pad = s.pad;
     a.dil = s.dil;
     a.in_slope = s.in_slope;
-    a.ntiles_per_b = mg_cdiv(s.Lout, 64 * NNB);
+    a.ntiles_per_b = mg_cdiv(s.Lout, (4 / MW) * 32 * NNB);
     a.ntiles_total = a.ntiles_per_b * s.B;
-    const int mtiles = mg_cdiv(s.Mrows, 64 * WM);
+    const int mtiles = mg_cdiv(s.Mrows, 32 * MW * WM);
     dim3 grid((unsigned)(a.ntiles_total * mtiles));
-    hipLaunchKernelGGL((conv_mfma_kernel<KW, STRIDE, CK, DILMAX, WM, NNB, Epi>), grid, dim3(256), 0, st, a, ep);
+    hipLaunchKernelGGL((conv_mfma_kernel<KW, STRIDE, CK, DILMAX, MW, WM, NNB, Epi>), grid, dim3(256), 0, st, a, ep);
     MG_LAUNCH_CHECK();
     return MG_OK;
 }
@@ -333,14 +386,23 @@ static int conv_launch_k(const ConvShape &s, const float *in, const float *in_ve
     // the packed form of <= 64 rows holds 2 blocks (WM = 1 only); wider ones are padded to 128 rows
     const bool must_wm1 = s.Mrows <= 64;
     auto wgs = [&](int wm, int nnb) { return (long)mg_cdiv(s.Mrows, 64 * wm) * mg_cdiv(s.Lout, 64 * nnb) * s.B; };
+    if (s.Mrows <= 32 && can_wm1) {   // one 32-row block: all 4 waves along the frame axis
+        // 256-frame tiles unless the slab would not fit the register staging (> 32 elements per thread)
+        constexpr bool big_slab = CK * (256 * STRIDE + (KW - 1) * DILMAX) > 32 * 256;
+        if constexpr (!big_slab) {
+            if ((long)mg_cdiv(s.Lout, 256) * s.B >= 512)
+                return conv_launch_t<KW, STRIDE, CK, DILMAX, 1, 1, 2, Epi>(s, in, in_vec, wp, ep, st);
+        }
+        return conv_launch_t<KW, STRIDE, CK, DILMAX, 1, 1, 1, Epi>(s, in, in_vec, wp, ep, st);
+    }
     int wm = must_wm1 ? 1 : 2, nnb = 2;
     if (wgs(wm, nnb) < 512) nnb = 1;
     if (wgs(wm, nnb) < 512 && wm == 2 && can_wm1) wm = 1;
     if (wm == 2)
-        return nnb == 2 ? conv_launch_t<KW, STRIDE, CK, DILMAX, 2, 2, Epi>(s, in, in_vec, wp, ep, st)
-                        : conv_launch_t<KW, STRIDE, CK, DILMAX, 2, 1, Epi>(s, in, in_vec, wp, ep, st);
-    return nnb == 2 ? conv_launch_t<KW, STRIDE, CK, DILMAX, 1, 2, Epi>(s, in, in_vec, wp, ep, st)
-                    : conv_launch_t<KW, STRIDE, CK, DILMAX, 1, 1, Epi>(s, in, in_vec, wp, ep, st);
+        return nnb == 2 ? conv_launch_t<KW, STRIDE, CK, DILMAX, 2, 2, 2, Epi>(s, in, in_vec, wp, ep, st)
+                        : conv_launch_t<KW, STRIDE, CK, DILMAX, 2, 2, 1, Epi>(s, in, in_vec, wp, ep, st);
+    return nnb == 2 ? conv_launch_t<KW, STRIDE, CK, DILMAX, 2, 1, 2, Epi>(s, in, in_vec, wp, ep, st)
+                    : conv_launch_t<KW, STRIDE, CK, DILMAX, 2, 1, 1, Epi>(s, in, in_vec, wp, ep, st);
 }
 
 // Dispatch on (K, stride, dilation); CK must match mg_conv_ck().  The path's own convolutions (K in

@@ -42,6 +42,33 @@ def pack_cached(w, mode=PACK_PLAIN):
     return p
 
 
+PACK_TPOSE = "tpose"   # polyphase ConvTranspose1d pack (pack_conv_transpose_weight)
+
+
+def pack_conv_transpose_weight(w):
+    """ConvTranspose1d weight [Ci, Co, 2u] (stride u, padding u/2) -> polyphase MFMA pack."""
+    L = _lib.lib()
+    w = w.detach().contiguous()
+    Ci, Co, K = w.shape
+    u = K // 2
+    n = L.mg_conv_transpose_packed_floats(Ci, Co, u) if K == 2 * u else 0
+    if n == 0:
+        raise _lib.MixganHipError("unsupported transposed-conv weight shape %s" % (tuple(w.shape),))
+    out = torch.empty(n, device=w.device, dtype=torch.float32)
+    check(L.mg_conv_transpose_pack(fptr(w), fptr(out), Ci, Co, u, stream_ptr()))
+    return out
+
+
+def conv_transpose1d_packed(x, packed, bias, Co, u, in_slope=1.0, alpha=1.0):
+    """alpha * conv_transpose1d(leaky_relu(x, in_slope), w, stride=u, padding=u/2) + bias; x [B,Ci,L] -> [B,Co,u*L]."""
+    L = _lib.lib()
+    B, Ci, Lin = x.shape
+    out = torch.empty(B, Co, u * Lin, device=x.device, dtype=torch.float32)
+    check(L.mg_conv_transpose1d_fwd(fptr(x), fptr(packed), fptr(bias, True), fptr(out), B, Ci, Lin, Co, u,
+                                    float(in_slope), float(alpha), stream_ptr()))
+    return out
+
+
 def conv1d_packed(x, packed, bias, Co, K, stride=1, padding=0, act=None, alpha=1.0, add=None, in_vec=None,
                   out=None, accumulate=False, Lout=None, dilation=1, in_slope=1.0, act_slope=0.0):
     """act: None | "relu" | "lrelu" (0.2) | "tanh" | "lrelu_s" (slope act_slope); in_slope: leaky ReLU

@@ -8,8 +8,9 @@ reference, so its checkpoints load unchanged (none ship with the reference: `.MI
 
 Kernel mapping: every Conv1d (k in {3,7,11}, dilation in {1,3,5}) is the MFMA implicit-GEMM conv with
 the pre-activation leaky ReLU applied while the input tile is staged and the post-activation / residual
-add in the epilogue; ConvTranspose1d (k = 2*stride) is zero insertion (with its leaky ReLU fused) plus
-a stride-1 convolution on the transposed, tap-flipped pack; the three ResBlocks of a stage accumulate into
+add in the epilogue; ConvTranspose1d (k = 2*stride) is a polyphase 3-tap GEMM over the input (leaky ReLU
+fused in staging, phases interleaved by the epilogue; other (k, stride) fall back to zero insertion plus a
+stride-1 convolution on the transposed, tap-flipped pack); the three ResBlocks of a stage accumulate into
 one buffer and the 1/3 is folded into the next convolution (leaky ReLU is positively homogeneous).
 Inference only (the vocoder is not trained on this path).
 """
@@ -54,7 +55,8 @@ class _WNConv(nn.Module):
         hit = self.__dict__.get("_mg_pack")
         if hit is None or hit[0] != key:
             with torch.no_grad():
-                hit = (key, ops.pack_conv_weight(self.effective_weight().contiguous(), mode))
+                w = self.effective_weight().contiguous()
+                hit = (key, ops.pack_conv_transpose_weight(w) if mode == ops.PACK_TPOSE else ops.pack_conv_weight(w, mode))
             self.__dict__["_mg_pack"] = hit
         return hit[1]
 
@@ -131,12 +133,15 @@ class Generator(nn.Module):
         for i, (u, k) in enumerate(zip(h.upsample_rates, h.upsample_kernel_sizes)):
             up = self.ups[i]
             co = c0 // (2 ** (i + 1))
-            L = x.shape[2]
-            pad = (k - u) // 2
-            z = ops.upsample_zero(x, u, (L - 1) * u + 1, slope=LRELU_SLOPE)       # lrelu + zero insertion
-            Lout = (L - 1) * u - 2 * pad + k
-            x = ops.conv1d_packed(z, up.packed(ops.PACK_DGRAD), up.bias.detach(), co, k, 1, k - 1 - pad, alpha=scale,
-                                  Lout=Lout)
+            if k == 2 * u and u in (2, 4, 8):     # polyphase: 3-tap GEMM with co*u rows, lrelu fused in staging
+                x = ops.conv_transpose1d_packed(x, up.packed(ops.PACK_TPOSE), up.bias.detach(), co, u,
+                                                in_slope=LRELU_SLOPE, alpha=scale)
+            else:                                 # general (k, u): lrelu + zero insertion, flipped stride-1 conv
+                L = x.shape[2]
+                pad = (k - u) // 2
+                z = ops.upsample_zero(x, u, (L - 1) * u + 1, slope=LRELU_SLOPE)
+                x = ops.conv1d_packed(z, up.packed(ops.PACK_DGRAD), up.bias.detach(), co, k, 1, k - 1 - pad,
+                                      alpha=scale, Lout=(L - 1) * u - 2 * pad + k)
             acc = torch.empty_like(x)
             for j in range(self.num_kernels):
                 self.resblocks[i * self.num_kernels + j].forward_cm(x, acc, j == 0)

@@ -98,6 +98,21 @@ def test_conv_transpose_by_zero_insertion(mg, K, u, Ci, Co, L):
     assert_close(y.cpu(), ref, 1e-5, "conv transpose")
 
 
+@pytest.mark.parametrize("u,Ci,Co,B,L", [(8, 512, 256, 2, 13), (8, 64, 32, 3, 133), (2, 128, 64, 2, 77), (2, 64, 32, 1, 1),
+                                          (4, 32, 16, 2, 300), (8, 24, 4, 1, 50), (2, 16, 2, 2, 700)])
+def test_conv_transpose_polyphase(mg, u, Ci, Co, B, L):
+    """mg_conv_transpose1d_fwd == alpha * F.conv_transpose1d(leaky_relu(x), w, None, u, u/2) + bias."""
+    gen = torch.Generator().manual_seed(u * 1000 + L)
+    x = torch.randn(B, Ci, L, generator=gen)
+    w = torch.randn(Ci, Co, 2 * u, generator=gen) / (2 * Ci) ** 0.5
+    b = torch.randn(Co, generator=gen)
+    ref = 0.5 * F.conv_transpose1d(F.leaky_relu(x, 0.1), w, None, u, u // 2) + b[None, :, None]
+    wp = mg.ops.pack_conv_transpose_weight(w.cuda())
+    y = mg.ops.conv_transpose1d_packed(x.cuda(), wp, b.cuda(), Co, u, in_slope=0.1, alpha=0.5)
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert_close(y.cpu(), ref, 1e-5, "polyphase conv transpose")
+
+
 def test_generator_cpu_input_fails_loudly(mg):
     G = mg.vocoder.Generator(_h())
     with pytest.raises(mg._lib.MixganHipError):
