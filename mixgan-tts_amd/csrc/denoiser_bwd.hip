@@ -23,25 +23,47 @@ struct EpiGateBwd {
     static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][NNB], int b, int mrow0, int l0w,
                                                int lane, int Lout)
     {
+        // loads of 8 rows x NNB frames first (clamped addresses), then the math and the predicated stores
         const int h = lane >> 5, c = lane & 31;
+        int lc[NNB];
+        bool lok[NNB];
+#pragma unroll
+        for (int j = 0; j < NNB; ++j) {
+            const int l = l0w + j * 32 + c;
+            lok[j] = l < Lout;
+            lc[j] = lok[j] ? l : Lout - 1;
+        }
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ch = mrow0 + i * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                if (ch >= p.C) continue;
-                const size_t so = ((size_t)b * p.C + ch) * Lout;
-                const size_t zo = ((size_t)b * 2 * p.C + ch) * Lout;
+            for (int half = 0; half < 2; ++half) {
+                float sv[8][NNB], tv[8][NNB];
+                size_t zo[8];
+                bool rok[8];
 #pragma unroll
-                for (int j = 0; j < NNB; ++j) {
-                    const int l = l0w + j * 32 + c;
-                    if (l < Lout) {
-                        const float dg = acc[i][j][r];
-                        const float s = p.sig[so + l], t = p.tnh[so + l];
-                        p.dz[zo + l] = dg * t * s * (1.f - s);                         // d/d gate pre-activation
-                        p.dz[zo + (size_t)p.C * Lout + l] = dg * s * (1.f - t * t);   // d/d filter pre-activation
+                for (int r = 0; r < 8; ++r) {
+                    const int rr = half * 8 + r;
+                    const int ch = mrow0 + i * 32 + 8 * (rr >> 2) + 4 * h + (rr & 3);
+                    rok[r] = ch < p.C;
+                    const int cc = rok[r] ? ch : p.C - 1;
+                    const size_t so = ((size_t)b * p.C + cc) * Lout;
+                    zo[r] = ((size_t)b * 2 * p.C + cc) * Lout;
+#pragma unroll
+                    for (int j = 0; j < NNB; ++j) {
+                        sv[r][j] = p.sig[so + lc[j]];
+                        tv[r][j] = p.tnh[so + lc[j]];
                     }
                 }
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int j = 0; j < NNB; ++j) {
+                        const float dg = acc[i][j][half * 8 + r], sg = sv[r][j], t = tv[r][j];
+                        if (rok[r] && lok[j]) {
+                            p.dz[zo[r] + lc[j]] = dg * t * sg * (1.f - sg);                         // d/d gate pre-activation
+                            p.dz[zo[r] + (size_t)p.C * Lout + lc[j]] = dg * sg * (1.f - t * t);   // d/d filter pre-activation
+                        }
+                    }
             }
         }
     }
@@ -60,23 +82,42 @@ struct EpiDhBwd {
     {
         const int h = lane >> 5, c = lane & 31;
         const float rs2 = 0.70710678118654752440f;
+        int lc[NNB];
+        bool lok[NNB];
+#pragma unroll
+        for (int j = 0; j < NNB; ++j) {
+            const int l = l0w + j * 32 + c;
+            lok[j] = l < Lout;
+            lc[j] = lok[j] ? l : Lout - 1;
+        }
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ch = mrow0 + i * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                if (ch >= p.C) continue;
-                float *dh = p.dh + (size_t)b * p.dh_bs + (size_t)ch * Lout;
-                float *dx = p.dout + ((size_t)b * 2 * p.C + ch) * Lout;
+            for (int half = 0; half < 2; ++half) {
+                float xv[8][NNB];
+                size_t ho[8], xo[8];
+                bool rok[8];
 #pragma unroll
-                for (int j = 0; j < NNB; ++j) {
-                    const int l = l0w + j * 32 + c;
-                    if (l < Lout) {
-                        const float v = acc[i][j][r];
-                        dh[l] = v;
-                        dx[l] = (v + dx[l]) * rs2;
-                    }
+                for (int r = 0; r < 8; ++r) {
+                    const int rr = half * 8 + r;
+                    const int ch = mrow0 + i * 32 + 8 * (rr >> 2) + 4 * h + (rr & 3);
+                    rok[r] = ch < p.C;
+                    const int cc = rok[r] ? ch : p.C - 1;
+                    ho[r] = (size_t)b * p.dh_bs + (size_t)cc * Lout;
+                    xo[r] = ((size_t)b * 2 * p.C + cc) * Lout;
+#pragma unroll
+                    for (int j = 0; j < NNB; ++j) xv[r][j] = p.dout[xo[r] + lc[j]];
                 }
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int j = 0; j < NNB; ++j) {
+                        const float v = acc[i][j][half * 8 + r];
+                        if (rok[r] && lok[j]) {
+                            p.dh[ho[r] + lc[j]] = v;
+                            p.dout[xo[r] + lc[j]] = (v + xv[r][j]) * rs2;
+                        }
+                    }
             }
         }
     }
