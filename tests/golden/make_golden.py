@@ -443,6 +443,91 @@ def main():
     arrs.update({"gain/" + k_: v_ for k_, v_ in gains.items()})
     save("hifigan", **arrs)
 
+    # (f2) data path: dataset.py Dataset / TextDataset collation + utils/tools.py to_device ---------------
+    print("dataset")
+    import tempfile as _tf
+    from dataset import Dataset as RefDataset, TextDataset as RefTextDataset
+    from text import text_to_sequence as ref_t2s
+    from utils.tools import to_device as ref_to_device
+    drng = np.random.default_rng(424242)
+    ddir = _tf.mkdtemp(prefix="mg_data_")
+    spks = ["spkA", "spkB", "spkC"]
+    with open(os.path.join(ddir, "speakers.json"), "w") as f:
+        json.dump({s_: i_ for i_, s_ in enumerate(spks)}, f)
+    with open(os.path.join(ddir, "stats.json"), "w") as f:
+        json.dump({"pitch": [-2.0, 8.0, 0.0, 1.0], "energy": [-1.5, 7.0, 0.0, 1.0]}, f)
+    for k_ in ("mel", "pitch", "energy", "duration", "phones_per_word", "attn_prior", "spker_embed"):
+        os.makedirs(os.path.join(ddir, k_))
+    phs = "HH AH0 L OW1 sp W ER1 D AA1 R K S IY1 T N Z spn M EY1 B".split()
+    arrs, lines = {}, []
+    for s_ in spks:
+        e_ = drng.standard_normal((1, 256)).astype(np.float32)
+        np.save(os.path.join(ddir, "spker_embed", "%s-spker_embed.npy" % s_), e_)
+        arrs["spk/" + s_] = e_
+    N_ITEMS = 11
+    for i_ in range(N_ITEMS):
+        base, s_ = "utt%02d" % i_, spks[i_ % 3]
+        nw = int(drng.integers(2, 6))
+        ppw = drng.integers(1, 4, nw).astype(np.int64)
+        n_ph = int(ppw.sum())
+        dur = drng.integers(1, 7, n_ph).astype(np.int64)
+        Lm = int(dur.sum())
+        item = {"mel": drng.uniform(-11.5, 2.0, (Lm, 80)).astype(np.float32),
+                "pitch": drng.standard_normal(Lm).astype(np.float64),       # np.save of a python-float list is float64
+                "energy": drng.standard_normal(Lm).astype(np.float32),
+                "duration": dur, "phones_per_word": ppw,
+                "attn_prior": drng.uniform(0, 1, (n_ph, Lm)).astype(np.float32)}
+        for k_, a_ in item.items():
+            np.save(os.path.join(ddir, k_, "%s-%s-%s.npy" % (s_, k_, base)), a_)
+            arrs["item%02d/%s" % (i_, k_)] = a_
+        text = "{" + " ".join(phs[int(j_)] for j_ in drng.integers(0, len(phs), n_ph)) + "}"
+        lines.append("%s|%s|%s|raw text %d" % (base, s_, text, i_))
+        arrs["item%02d/phone_ids" % i_] = np.array(ref_t2s(text, ["english_cleaners"]), dtype=np.int64)
+    with open(os.path.join(ddir, "train.txt"), "w", encoding="utf-8") as f:
+        f.write("\n".join(lines) + "\n")
+    arrs["meta_lines"] = np.array(lines)
+
+    def _dump(prefix, batchs):
+        for b_, tup in enumerate(batchs):
+            for j_, x_ in enumerate(tup):
+                key = "%s/b%d/s%02d" % (prefix, b_, j_)
+                if x_ is None:
+                    continue
+                if torch.is_tensor(x_):
+                    arrs[key] = x_.numpy()
+                    arrs[key + "_torch_dtype"] = np.array(str(x_.dtype))
+                elif isinstance(x_, list):
+                    arrs[key] = np.array(x_)
+                else:
+                    arrs[key] = np.asarray(x_)
+        arrs[prefix + "/n_batches"] = np.array(len(batchs))
+
+    dpre = {"dataset": "Synth", "path": {"preprocessed_path": ddir},
+            "preprocessing": {"text": {"text_cleaners": ["english_cleaners"]}, "speaker_embedder": "none"}}
+    dtrain = {"optimizer": {"batch_size": 4, "batch_size_shallow": 3}}
+    # (1) train.py:31-33 configuration: sort=True, drop_last=True, naive (batch 4): 11 items -> 2 sub-batches
+    ds = RefDataset("train.txt", types.SimpleNamespace(model="naive"), dpre, {"multi_speaker": False}, dtrain,
+                    sort=True, drop_last=True)
+    _dump("sorted_drop", ds.collate_fn([ds[i_] for i_ in range(N_ITEMS)]))
+    # (2) evaluate.py configuration: sort=False, drop_last=False, shallow (batch 3), speaker embeddings loaded
+    dpre2 = json.loads(json.dumps(dpre))
+    dpre2["preprocessing"]["speaker_embedder"] = "DeepSpeaker"
+    ds2 = RefDataset("train.txt", types.SimpleNamespace(model="shallow"), dpre2, {"multi_speaker": True}, dtrain,
+                     sort=False, drop_last=False)
+    order2 = [7, 2, 9, 0, 5, 10, 3]
+    b2 = ds2.collate_fn([ds2[i_] for i_ in order2])
+    _dump("plain_keep", b2)
+    arrs["plain_keep/order"] = np.array(order2)
+    _dump("plain_keep_dev", [ref_to_device(t_, torch.device("cpu")) for t_ in b2])
+    # (3) TextDataset (synthesize.py:258)
+    tds = RefTextDataset(os.path.join(ddir, "train.txt"), dpre2, {"multi_speaker": True})
+    order3 = [4, 1, 8]
+    b3 = tds.collate_fn([tds[i_] for i_ in order3])
+    _dump("text", [b3])
+    arrs["text/order"] = np.array(order3)
+    _dump("text_dev", [ref_to_device(b3, torch.device("cpu"))])
+    save("dataset", **arrs)
+
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(MANIFEST, f, indent=0, sort_keys=True)
     print("manifest written")

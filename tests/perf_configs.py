@@ -201,8 +201,82 @@ def stock_eager_bench():
                           "ours_ms": round(to * 1e3, 2), "speedup": round(ts / to, 2), "max_abs_diff": err}), flush=True)
 
 
+def data_bench():
+    """groups of 4 x 8 utterances (~800-1000 frames each) from a synthetic
+    preprocessed_data tree: the reference's synchronous loop (np.load + collate + to_device on the training
+    thread) vs the prefetching loader (loads / pinned staging / copies hidden behind the consumer)."""
+    import types
+    from mixgan_tts_amd import data as D
+    rng = np.random.default_rng(5)
+    d = tempfile.mkdtemp(prefix="mg_data_")
+    for k in D.Dataset.KINDS:
+        os.makedirs(os.path.join(d, k))
+    with open(os.path.join(d, "speakers.json"), "w") as f:
+        json.dump({"spk": 0}, f)
+    lines, ids = [], {}
+    for i in range(256):
+        nw = int(rng.integers(12, 20))
+        ppw = rng.integers(2, 6, nw)
+        n_ph = int(ppw.sum())
+        dur = rng.integers(8, 22, n_ph)
+        Lm = int(dur.sum())
+        arrs = {"mel": rng.uniform(-11.5, 2, (Lm, 80)).astype(np.float32), "pitch": rng.standard_normal(Lm),
+                "energy": rng.standard_normal(Lm).astype(np.float32), "duration": dur, "phones_per_word": ppw,
+                "attn_prior": rng.uniform(0, 1, (n_ph, Lm)).astype(np.float32)}
+        for k, a in arrs.items():
+            np.save(os.path.join(d, k, "spk-%s-u%03d.npy" % (k, i)), a)
+        text = "t%d" % i
+        ids[text] = rng.integers(1, 100, n_ph)
+        lines.append("u%03d|spk|%s|raw" % (i, text))
+    with open(os.path.join(d, "train.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    pre = {"dataset": "Synth", "path": {"preprocessed_path": d},
+           "preprocessing": {"text": {"text_cleaners": []}, "speaker_embedder": "none"}}
+    ds = D.Dataset("train.txt", types.SimpleNamespace(model="naive"), pre, {"multi_speaker": False},
+                   {"optimizer": {"batch_size": 8}}, sort=True, drop_last=True,
+                   text_to_sequence=lambda t, c: ids[t].tolist())
+    smp = D.RankShardSampler(len(ds), 32, seed=1)
+    dev = torch.device("cuda", 0)
+    work = torch.randn(4096, 4096, device=dev)
+
+    def run(loader_kind, sync_each):
+        def consume(batchs):   # stand-in for the training step: 4 sub-batches x 8 GEMMs of GPU work per group
+            for k in range(4):
+                for _ in range(8):
+                    (work @ work).sum()
+                if batchs:
+                    batchs[k][11].sum()
+                if sync_each:  # a loop that reads its losses back every step (`.item()`)
+                    torch.cuda.synchronize()
+        if loader_kind == "none":
+            it = ([] for _ in smp)
+        elif loader_kind == "sync":
+            it = ([D.to_device(b, dev) for b in ds.collate_fn([ds[i] for i in idxs])] for idxs in smp)
+        else:
+            it = iter(loaders[loader_kind])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for batchs in it:
+            consume(batchs)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3
+
+    loaders = {"prefetch_w1": D.PrefetchLoader(ds, smp, dev, depth=2, workers=1),
+               "prefetch_w2": D.PrefetchLoader(ds, smp, dev, depth=3, workers=2)}
+    out = {"config": "f2 data path: 8 groups of 4x8 utterances (~900 frames), warm page cache"}
+    for sync_each in (False, True):
+        tag = "step_syncs" if sync_each else "async_steps"
+        for kind in ("none", "sync", "prefetch_w1", "prefetch_w2"):
+            run(kind, sync_each)       # warm-up epoch (page cache, allocator, pinned arenas)
+            t = min(run(kind, sync_each) for _ in range(2))
+            out["%s/%s_ms" % (tag, {"none": "gpu_work_only", "sync": "reference_style_loop"}.get(kind, kind))] = round(t, 1)
+    print(json.dumps(out), flush=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "stock":
+    if len(sys.argv) > 1 and sys.argv[1] == "data":
+        data_bench()
+    elif len(sys.argv) > 1 and sys.argv[1] == "stock":
         stock_eager_bench()
     elif len(sys.argv) > 1 and sys.argv[1] == "lingops":
         lingops_bench()
