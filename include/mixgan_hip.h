@@ -238,6 +238,44 @@ int mg_linear_small_fwd(const float *x, const float *W, float *out, int B, int N
 int mg_linear_small_bwd(const float *g, const float *x, const float *W, float *dx, float *dW, int B,
                         int N, int K, void *stream);
 
+/* ------------------------------------------------------------------ aux pre-training
+ * Strided batched fp32 GEMM on the MFMA: C[z](m,n) (+)= alpha * sum_k A[z](m,k) B[z](k,n), z = b*heads + h,
+ * operand z at base + b*x_bs + h*x_hs; A(m,k) at m*a_ms + k*a_ks, B(k,n) at k*b_ks + n*b_ns (one stride of each
+ * operand must be 1), C row-major with row stride c_ms.  The six contractions of train-mode attention and its
+ * backward (transformer/Modules.py:16-23) are calls of this on the channel-major q/k/v and the kept [B*H,L,L]
+ * probabilities. */
+int mg_bgemm(const float *A, const float *B, float *C, int M, int N, int K, int batch, int heads, long a_ms, long a_ks,
+             long a_bs, long a_hs, long b_ks, long b_ns, long b_bs, long b_hs, long c_ms, long c_bs, long c_hs,
+             float alpha, int accumulate, void *stream);
+/* In place: S [B*H, L, L] -> softmax over keys of scale*S with padded keys (key_pad [B, L] != 0) at -inf. */
+int mg_softmax_rows_fwd(float *S, const uint8_t *key_pad, int B, int H, int L, float scale, void *stream);
+/* In place on dP: dS = scale * P o (dP - rowsum(dP o P)). */
+int mg_softmax_rows_bwd(const float *P, float *dP, int B, int H, int L, float scale, void *stream);
+/* Train-mode post-LayerNorm (transformer/SubLayers.py:54-55,90-91): pre = a * keep * drop_scale + res (keep: uint8
+ * [B,C,L] dropout keep-mask or NULL), out = pad ? 0 : LN_c(pre) * gamma + beta; `pre` is saved for the backward. */
+int mg_layernorm_cm_train_fwd(const float *a, const uint8_t *keep, float drop_scale, const float *res,
+                              const float *gamma, const float *beta, const uint8_t *pad, float *pre, float *out, int B,
+                              int C, int L, float eps, void *stream);
+/* d_pre (= d res), d_a = d_pre * keep * drop_scale (optional), dgamma / dbeta [C] ACCUMULATED (atomics). */
+int mg_layernorm_cm_bwd(const float *pre, const float *dy, const float *gamma, const uint8_t *pad, const uint8_t *keep,
+                        float drop_scale, float *d_pre, float *d_a, float *dgamma, float *dbeta, int B, int C, int L,
+                        float eps, void *stream);
+/* BatchNorm1d with batch statistics + tanh + dropout of PostNet (transformer/Layers.py:131-134) on [B,C,L]:
+ * mg_bn_stats -> per-channel mean and biased variance over (B,L);  mg_bn_act_fwd: y = act((x-mean)*invstd*gamma+beta)
+ * (act MG_ACT_NONE|MG_ACT_TANH; y saved when tanh), out = y * keep * drop_scale;  backward in two passes:
+ * _reduce -> dbeta = sum dpre, dgamma = sum dpre*xhat (dpre = dout*keep*drop_scale*act'(y)), then _apply ->
+ * dx = gamma*invstd*(dpre - dbeta*inv_count - xhat*dgamma*inv_count)  (all-reduce the two vectors between the
+ * passes for cross-rank statistics). */
+int mg_bn_stats(const float *x, float *mean, float *var, int B, int C, int L, void *stream);
+int mg_bn_act_fwd(const float *x, const float *mean, const float *invstd, const float *gamma, const float *beta,
+                  const uint8_t *keep, float drop_scale, int act, float *y, float *out, int B, int C, int L, void *stream);
+int mg_bn_act_bwd_reduce(const float *dout, const uint8_t *keep, float drop_scale, const float *y, const float *x,
+                         const float *mean, const float *invstd, int act, float *dgamma, float *dbeta, int B, int C, int L,
+                         void *stream);
+int mg_bn_act_bwd_apply(const float *dout, const uint8_t *keep, float drop_scale, const float *y, const float *x,
+                        const float *mean, const float *invstd, const float *gamma, const float *dgamma,
+                        const float *dbeta, float inv_count, int act, float *dx, int B, int C, int L, void *stream);
+
 /* ------------------------------------------------------------------ losses on the path (model/loss.py)
  * mg_loss_sum: out[0] = sum (a-c)^2 (mode 0: F.mse_loss against a constant label, loss.py:14-19)
  *              or sum |a-b| (mode 1: F.l1_loss numerator, loss.py:221-227); the caller divides by n.

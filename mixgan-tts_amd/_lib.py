@@ -11,7 +11,8 @@ _LIB = None
 EXPORTS = (
     "mg_version", "mg_error_string",
     "mg_conv_packed_floats", "mg_conv_pack", "mg_conv_pack_at", "mg_conv1d_fwd", "mg_conv1d_fwd_ex",
-    "mg_upsample_zero_act", "mg_conv_transpose_packed_floats", "mg_conv_transpose_pack", "mg_conv_transpose1d_fwd",
+    "mg_upsample_zero_act", "mg_bgemm", "mg_softmax_rows_fwd", "mg_softmax_rows_bwd", "mg_layernorm_cm_train_fwd",
+    "mg_layernorm_cm_bwd", "mg_bn_stats", "mg_bn_act_fwd", "mg_bn_act_bwd_reduce", "mg_bn_act_bwd_apply", "mg_conv_transpose_packed_floats", "mg_conv_transpose_pack", "mg_conv_transpose1d_fwd",
     "mg_conv1d_wgrad_scratch_floats", "mg_conv1d_wgrad", "mg_conv1d_wgrad_strided", "mg_rowsum",
     "mg_diffuse_fwd", "mg_posterior_sample_fwd", "mg_posterior_sample_bwd", "mg_spec_affine", "mg_transpose_bml",
     "mg_denoiser_packed_floats", "mg_denoiser_pack", "mg_denoiser_workspace_floats", "mg_denoiser_fwd",
@@ -62,7 +63,7 @@ def lib():
 
 def _declare(L):
     """argtypes/restype for every export of include/mixgan_hip.h."""
-    vp, i, f, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+    vp, i, f, sz, lg = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_long
     dp = ctypes.POINTER(DenoiserDims)
     sig = {
         "mg_version": (i, []),
@@ -72,6 +73,15 @@ def _declare(L):
         "mg_conv1d_fwd": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, f, i, vp]),
         "mg_conv1d_fwd_ex": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, f, i, f, f, i, vp]),
         "mg_upsample_zero_act": (i, [vp, vp, i, i, i, i, f, vp]),
+        "mg_bgemm": (i, [vp, vp, vp, i, i, i, i, i] + [lg] * 11 + [f, i, vp]),
+        "mg_softmax_rows_fwd": (i, [vp, vp, i, i, i, f, vp]),
+        "mg_softmax_rows_bwd": (i, [vp, vp, i, i, i, f, vp]),
+        "mg_layernorm_cm_train_fwd": (i, [vp, vp, f, vp, vp, vp, vp, vp, vp, i, i, i, f, vp]),
+        "mg_layernorm_cm_bwd": (i, [vp, vp, vp, vp, vp, f, vp, vp, vp, vp, i, i, i, f, vp]),
+        "mg_bn_stats": (i, [vp, vp, vp, i, i, i, vp]),
+        "mg_bn_act_fwd": (i, [vp, vp, vp, vp, vp, vp, f, i, vp, vp, i, i, i, vp]),
+        "mg_bn_act_bwd_reduce": (i, [vp, vp, f, vp, vp, vp, vp, i, vp, vp, i, i, i, vp]),
+        "mg_bn_act_bwd_apply": (i, [vp, vp, f, vp, vp, vp, vp, vp, vp, vp, f, i, vp, i, i, i, vp]),
         "mg_conv_transpose_packed_floats": (sz, [i, i, i]),
         "mg_conv_transpose_pack": (i, [vp, vp, i, i, i, vp]),
         "mg_conv_transpose1d_fwd": (i, [vp, vp, vp, vp, i, i, i, i, i, f, f, vp]),

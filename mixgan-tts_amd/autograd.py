@@ -211,3 +211,102 @@ class _CatTransposeFn(torch.autograd.Function):
 def cat_transpose(a, b):
     _require_cuda(a, b)
     return _CatTransposeFn.apply(a, b)
+
+
+# --------------------------------------------------------------------------------------------------
+# aux pre-training: train-mode FFT-block / PostNet pieces with their backward
+# --------------------------------------------------------------------------------------------------
+class _AttentionTrainFn(torch.autograd.Function):
+    """softmax(QK^T / sqrt(d) | key mask) V on channel-major qkv [B, 3HD, L], probabilities kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, qkv, key_pad, n_head, d):
+        _require_cuda(qkv)
+        qkv = qkv.contiguous()
+        out, P = ops.attention_train_fwd(qkv, key_pad, n_head, d)
+        ctx.save_for_backward(qkv, P)
+        ctx.cfg = (n_head, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, P = ctx.saved_tensors
+        return ops.attention_train_bwd(qkv, P, g.contiguous(), *ctx.cfg), None, None, None
+
+
+def attention_train(qkv, key_pad, n_head, d):
+    return _AttentionTrainFn.apply(qkv, key_pad, n_head, d)
+
+
+class _LayerNormTrainFn(torch.autograd.Function):
+    """out = pad ? 0 : LayerNorm_c(dropout(a) + res) on [B, C, L]; keep: uint8 keep-mask or None."""
+
+    @staticmethod
+    def forward(ctx, a, res, gamma, beta, pad, keep, drop_scale, eps):
+        _require_cuda(a, res)
+        out, pre = ops.layernorm_cm_train(a.contiguous(), keep, drop_scale, res.contiguous(), gamma.detach(),
+                                          beta.detach(), pad, eps)
+        ctx.save_for_backward(pre, gamma, pad if pad is not None else pre.new_empty(0, dtype=torch.uint8),
+                              keep if keep is not None else pre.new_empty(0, dtype=torch.uint8))
+        ctx.cfg = (pad is not None, keep is not None, drop_scale, eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pre, gamma, pad, keep = ctx.saved_tensors
+        has_pad, has_keep, scale, eps = ctx.cfg
+        d_pre, d_a, dg, db = ops.layernorm_cm_bwd(pre, g.contiguous(), gamma.detach(), pad if has_pad else None,
+                                                  keep if has_keep else None, scale, eps)
+        return d_a, d_pre, dg, db, None, None, None, None
+
+
+def layernorm_train(a, res, gamma, beta, pad, keep, drop_scale, eps):
+    return _LayerNormTrainFn.apply(a, res, gamma, beta, pad, keep, drop_scale, eps)
+
+
+class _BatchNormActFn(torch.autograd.Function):
+    """dropout(act(BatchNorm1d(x))) with batch statistics on [B, C, L].  Returns (out, mean, biased var); with a
+    process group the statistics -- and in the backward the two per-channel sums -- are all-reduced (SyncBN)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, keep, drop_scale, act, eps, group):
+        _require_cuda(x)
+        x = x.contiguous()
+        mean, var = ops.bn_stats(x)
+        count = x.shape[0] * x.shape[2]
+        if group is not None:
+            import torch.distributed as dist
+            world = dist.get_world_size(group)
+            packed = torch.stack([mean, var + mean * mean])          # E[x], E[x^2]; equal counts per rank
+            dist.all_reduce(packed, group=group)
+            mean = packed[0] / world
+            var = (packed[1] / world - mean * mean).clamp_min_(0.0)
+            count *= world
+        invstd = torch.rsqrt(var + eps)
+        out, y = ops.bn_act_fwd(x, mean, invstd, gamma.detach(), beta.detach(), keep, drop_scale, act)
+        ctx.save_for_backward(x, mean, invstd, gamma, y if y is not None else x.new_empty(0),
+                              keep if keep is not None else x.new_empty(0, dtype=torch.uint8))
+        ctx.cfg = (keep is not None, drop_scale, act, count, group)
+        ctx.mark_non_differentiable(mean, var)
+        return out, mean, var
+
+    @staticmethod
+    def backward(ctx, g, _gm, _gv):
+        x, mean, invstd, gamma, y, keep = ctx.saved_tensors
+        has_keep, scale, act, count, group = ctx.cfg
+        g = g.contiguous()
+        keep = keep if has_keep else None
+        y = y if act == "tanh" else None
+        dg, db = ops.bn_act_bwd_reduce(g, keep, scale, y, x, mean, invstd, act)
+        dg_all, db_all = dg, db
+        if group is not None:
+            import torch.distributed as dist
+            packed = torch.stack([dg, db])
+            dist.all_reduce(packed, group=group)
+            dg_all, db_all = packed[0], packed[1]
+        dx = ops.bn_act_bwd_apply(g, keep, scale, y, x, mean, invstd, gamma.detach(), dg_all, db_all, 1.0 / count, act)
+        return dx, dg, db, None, None, None, None, None
+
+
+def batchnorm_act(x, gamma, beta, keep, drop_scale, act, eps, group=None):
+    return _BatchNormActFn.apply(x, gamma, beta, keep, drop_scale, act, eps, group)

@@ -280,3 +280,113 @@ def layernorm_cm(a, res, gamma, beta, pad, eps=1e-5):
     check(L.mg_layernorm_cm_fwd(fptr(a), fptr(res, True), fptr(gamma), fptr(beta), iptr(pad, torch.uint8, True),
                                 fptr(out), B, C, Lf, float(eps), stream_ptr()))
     return out
+
+
+# ------------------------------------------------------------------ aux pre-training (train_ops.hip, bgemm.hip)
+def _u8(t, allow_none=True):
+    return iptr(t, torch.uint8, allow_none)
+
+
+def attention_train_fwd(qkv, key_pad, n_head, d):
+    """Train-mode attention keeping the probabilities: qkv [B,3HD,L] -> (out [B,HD,L], P [B*H,L,L])."""
+    Lb = _lib.lib()
+    B, _, L = qkv.shape
+    HD, scale, st = n_head * d, float(d) ** -0.5, stream_ptr()
+    P = torch.empty(B * n_head, L, L, device=qkv.device, dtype=torch.float32)
+    q, k, v = qkv, qkv[:, HD:], qkv[:, 2 * HD:]
+    bs, hs = 3 * HD * L, d * L
+    # S[q,k] = sum_d Q[d,q] K[d,k]
+    check(Lb.mg_bgemm(ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(k.data_ptr()), fptr(P), L, L, d, B, n_head,
+                      1, L, bs, hs, L, 1, bs, hs, L, n_head * L * L, L * L, 1.0, 0, st))
+    check(Lb.mg_softmax_rows_fwd(fptr(P), _u8(key_pad), B, n_head, L, scale, st))
+    out = torch.empty(B, HD, L, device=qkv.device, dtype=torch.float32)
+    # O[d,q] = sum_k V[d,k] P[q,k]
+    check(Lb.mg_bgemm(ctypes.c_void_p(v.data_ptr()), fptr(P), fptr(out), d, L, L, B, n_head,
+                      L, 1, bs, hs, 1, L, n_head * L * L, L * L, L, HD * L, d * L, 1.0, 0, st))
+    return out, P
+
+
+def attention_train_bwd(qkv, P, d_out, n_head, d):
+    """-> d_qkv [B,3HD,L]."""
+    Lb = _lib.lib()
+    B, _, L = qkv.shape
+    HD, scale, st = n_head * d, float(d) ** -0.5, stream_ptr()
+    q, k, v = qkv, qkv[:, HD:], qkv[:, 2 * HD:]
+    bs, hs = 3 * HD * L, d * L
+    pbs, phs = n_head * L * L, L * L
+    dqkv = torch.empty_like(qkv)
+    dq, dk, dv = dqkv, dqkv[:, HD:], dqkv[:, 2 * HD:]
+    cp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    # dV[d,k] = sum_q dO[d,q] P[q,k]
+    check(Lb.mg_bgemm(fptr(d_out), fptr(P), cp(dv), d, L, L, B, n_head, L, 1, HD * L, d * L, L, 1, pbs, phs,
+                      L, bs, hs, 1.0, 0, st))
+    # dP[q,k] = sum_d dO[d,q] V[d,k]
+    dS = torch.empty_like(P)
+    check(Lb.mg_bgemm(fptr(d_out), cp(v), fptr(dS), L, L, d, B, n_head, 1, L, HD * L, d * L, L, 1, bs, hs,
+                      L, pbs, phs, 1.0, 0, st))
+    check(Lb.mg_softmax_rows_bwd(fptr(P), fptr(dS), B, n_head, L, scale, st))
+    # dQ[d,q] = sum_k K[d,k] dS[q,k];  dK[d,k] = sum_q Q[d,q] dS[q,k]
+    check(Lb.mg_bgemm(cp(k), fptr(dS), cp(dq), d, L, L, B, n_head, L, 1, bs, hs, 1, L, pbs, phs, L, bs, hs, 1.0, 0, st))
+    check(Lb.mg_bgemm(cp(q), fptr(dS), cp(dk), d, L, L, B, n_head, L, 1, bs, hs, L, 1, pbs, phs, L, bs, hs, 1.0, 0, st))
+    return dqkv
+
+
+def layernorm_cm_train(a, keep, drop_scale, res, gamma, beta, pad, eps=1e-5):
+    Lb = _lib.lib()
+    B, C, L = a.shape
+    pre, out = torch.empty_like(a), torch.empty_like(a)
+    check(Lb.mg_layernorm_cm_train_fwd(fptr(a), _u8(keep), float(drop_scale), fptr(res, True), fptr(gamma), fptr(beta),
+                                       _u8(pad), fptr(pre), fptr(out), B, C, L, float(eps), stream_ptr()))
+    return out, pre
+
+
+def layernorm_cm_bwd(pre, dy, gamma, pad, keep, drop_scale, eps=1e-5):
+    """-> (d_pre, d_a, dgamma, dbeta)."""
+    Lb = _lib.lib()
+    B, C, L = pre.shape
+    d_pre = torch.empty_like(pre)
+    d_a = torch.empty_like(pre) if keep is not None else None
+    dg = torch.zeros(C, device=pre.device, dtype=torch.float32)
+    db = torch.zeros(C, device=pre.device, dtype=torch.float32)
+    check(Lb.mg_layernorm_cm_bwd(fptr(pre), fptr(dy), fptr(gamma), _u8(pad), _u8(keep), float(drop_scale), fptr(d_pre),
+                                 fptr(d_a, True), fptr(dg), fptr(db), B, C, L, float(eps), stream_ptr()))
+    return d_pre, (d_a if d_a is not None else d_pre), dg, db
+
+
+def bn_stats(x):
+    Lb = _lib.lib()
+    B, C, L = x.shape
+    mean = torch.empty(C, device=x.device, dtype=torch.float32)
+    var = torch.empty(C, device=x.device, dtype=torch.float32)
+    check(Lb.mg_bn_stats(fptr(x), fptr(mean), fptr(var), B, C, L, stream_ptr()))
+    return mean, var
+
+
+def bn_act_fwd(x, mean, invstd, gamma, beta, keep, drop_scale, act):
+    Lb = _lib.lib()
+    B, C, L = x.shape
+    y = torch.empty_like(x) if act == "tanh" else None
+    out = torch.empty_like(x)
+    check(Lb.mg_bn_act_fwd(fptr(x), fptr(mean), fptr(invstd), fptr(gamma), fptr(beta), _u8(keep), float(drop_scale),
+                           ACT[act], fptr(y, True), fptr(out), B, C, L, stream_ptr()))
+    return out, y
+
+
+def bn_act_bwd_reduce(dout, keep, drop_scale, y, x, mean, invstd, act):
+    Lb = _lib.lib()
+    B, C, L = x.shape
+    dg = torch.empty(C, device=x.device, dtype=torch.float32)
+    db = torch.empty(C, device=x.device, dtype=torch.float32)
+    check(Lb.mg_bn_act_bwd_reduce(fptr(dout), _u8(keep), float(drop_scale), fptr(y, True), fptr(x), fptr(mean),
+                                  fptr(invstd), ACT[act], fptr(dg), fptr(db), B, C, L, stream_ptr()))
+    return dg, db
+
+
+def bn_act_bwd_apply(dout, keep, drop_scale, y, x, mean, invstd, gamma, dg, db, inv_count, act):
+    Lb = _lib.lib()
+    B, C, L = x.shape
+    dx = torch.empty_like(x)
+    check(Lb.mg_bn_act_bwd_apply(fptr(dout), _u8(keep), float(drop_scale), fptr(y, True), fptr(x), fptr(mean),
+                                 fptr(invstd), fptr(gamma), fptr(dg), fptr(db), float(inv_count), ACT[act], fptr(dx),
+                                 B, C, L, stream_ptr()))
+    return dx

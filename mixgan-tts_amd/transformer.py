@@ -6,9 +6,11 @@ Internally everything runs channel-major [B, C, L] (the conv kernels' layout): Q
 k=1 GEMM with 768 output rows, attention is the streaming-softmax MFMA kernel, the k=9 FFN conv
 and the PostNet convs are the generic conv kernel (eval-mode BatchNorm folded into weights/bias).
 
-Train mode (dropout p=0.2 / 0.5, BatchNorm batch statistics) belongs to aux pre-training, a
-"next" row of SURVEY.md section 8f: forward() raises in train mode rather than silently
-evaluating without dropout.
+Train mode (aux pre-training): dropout p = decoder_dropout after the attention `fc`
+and after the FFN (fused in front of the LayerNorm kernel), attention with the probabilities kept for the
+backward (batched MFMA GEMMs), PostNet with BatchNorm batch statistics + tanh + dropout 0.5, and the backward
+of every piece in the HIP library (autograd.py only chains them).  Dropout keep-masks come from `dropout_fn`
+(module attribute; default: `torch.rand(shape) >= p` on the device) so tests can inject the reference's masks.
 """
 import math
 
@@ -16,8 +18,23 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import ops, _lib
+from . import ops, _lib, autograd as ag
 from .blocks import _ConvParams
+
+
+def default_dropout_fn(shape, p, device):
+    """uint8 keep-mask (1 = keep) for nn.Dropout(p) / F.dropout(p)."""
+    return (torch.rand(shape, device=device) >= p).to(torch.uint8)
+
+
+DROPOUT_FN = None    # module-wide override of the keep-mask source (tests replay the reference's masks through it)
+
+
+def _keep_mask(module, shape, p, device):
+    if p <= 0.0:
+        return None, 1.0
+    fn = getattr(module, "dropout_fn", None) or DROPOUT_FN or default_dropout_fn
+    return fn(shape, p, device).to(device=device, dtype=torch.uint8).contiguous(), 1.0 / (1.0 - p)
 
 
 def get_sinusoid_encoding_table(n_position, d_hid, padding_idx=None):
@@ -44,12 +61,6 @@ class _Linear(nn.Module):
         nn.init.uniform_(self.bias, -bound, bound)
 
 
-def _require_eval(m):
-    if m.training:
-        raise NotImplementedError(
-            "%s: train-mode forward (dropout / BatchNorm batch statistics) is not on the HIP path yet; "
-            "call .eval() (inference of --model shallow) -- aux pre-training is a later row" % type(m).__name__)
-
 
 class MultiHeadAttention(nn.Module):
     """transformer/SubLayers.py:8-57."""
@@ -67,7 +78,8 @@ class MultiHeadAttention(nn.Module):
     def forward_cm(self, x, pad8, fill=False):
         """x [B, D, L] channel-major, pad8 uint8 [B, L] -> LayerNorm(fc(attn) + x), [B, D, L].
         fill=True also zeroes padded frames (the masked_fill of Layers.py:25)."""
-        _require_eval(self)
+        if self.training:
+            return self._forward_cm_train(x, pad8, fill)
         wq = torch.cat([ops.pack_cached(w.weight[:, :, None]) for w in (self.w_qs, self.w_ks, self.w_vs)])
         bq = torch.cat([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias]).detach()
         D = self.w_qs.weight.shape[1]
@@ -76,6 +88,17 @@ class MultiHeadAttention(nn.Module):
         y = ops.conv1d_packed(att, ops.pack_cached(self.fc.weight[:, :, None]), self.fc.bias.detach(), D, 1)
         return ops.layernorm_cm(y, x, self.layer_norm.weight.detach(), self.layer_norm.bias.detach(),
                                 pad8 if fill else None, self.layer_norm.eps)
+
+
+    def _forward_cm_train(self, x, pad8, fill):
+        w = torch.cat([self.w_qs.weight, self.w_ks.weight, self.w_vs.weight])[:, :, None]
+        b = torch.cat([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias])
+        qkv = ag.conv1d(x, w, b)
+        att = ag.attention_train(qkv, pad8, self.n_head, self.d_k)
+        y = ag.conv1d(att, self.fc.weight[:, :, None], self.fc.bias)
+        keep, scale = _keep_mask(self, tuple(y.shape), self.dropout_p, y.device)
+        return ag.layernorm_train(y, x, self.layer_norm.weight, self.layer_norm.bias, pad8 if fill else None, keep,
+                                  scale, self.layer_norm.eps)
 
 
 class PositionwiseFeedForward(nn.Module):
@@ -90,8 +113,13 @@ class PositionwiseFeedForward(nn.Module):
         self.dropout_p = dropout
 
     def forward_cm(self, x, pad8):
-        _require_eval(self)
         k = self.kernel_size
+        if self.training:
+            h = ag.conv1d(x, self.w_1.weight, self.w_1.bias, 1, (k - 1) // 2, "relu")
+            y = ag.conv1d(h, self.w_2.weight, self.w_2.bias)
+            keep, scale = _keep_mask(self, tuple(y.shape), self.dropout_p, y.device)
+            return ag.layernorm_train(y, x, self.layer_norm.weight, self.layer_norm.bias, pad8, keep, scale,
+                                      self.layer_norm.eps)
         h = ops.conv1d_packed(x, ops.pack_cached(self.w_1.weight), self.w_1.bias.detach(), self.w_1.weight.shape[0], k,
                               1, (k - 1) // 2, "relu")
         y = ops.conv1d_packed(h, ops.pack_cached(self.w_2.weight), self.w_2.bias.detach(), self.w_2.weight.shape[0], 1)
@@ -116,6 +144,8 @@ class FFTBlock(nn.Module):
         if not enc_input.is_cuda:
             raise _lib.MixganHipError("FFTBlock.forward on %s: the HIP path has no CPU fallback" % enc_input.device)
         pad8 = mask.to(torch.uint8).contiguous() if mask is not None else None
+        if self.training:
+            return ag.transpose_to_blm(self.forward_cm(ag.transpose_to_bml(enc_input), pad8)), None
         with torch.no_grad():
             x = ops.transpose_bml(enc_input.detach().contiguous(), False)
             y = self.forward_cm(x, pad8)
@@ -142,10 +172,17 @@ class Decoder(nn.Module):
     def forward_cm(self, enc_seq, mask):
         """enc_seq [B, L, D], mask bool [B, L] True = pad -> channel-major [B, D, L'] and the (possibly
         truncated) pad mask."""
-        _require_eval(self)
         if not enc_seq.is_cuda:
             raise _lib.MixganHipError("Decoder.forward on %s: the HIP path has no CPU fallback" % enc_seq.device)
         B, L = enc_seq.shape[0], enc_seq.shape[1]
+        if self.training:          # Models.py:153-162: clip to max_seq_len, stored table
+            L = min(L, self.max_seq_len)
+            x = enc_seq[:, :L, :] + self.position_enc[:, :L, :]
+            pad8 = mask[:, :L].to(torch.uint8).contiguous()
+            y = ag.transpose_to_bml(x)
+            for layer in self.layer_stack:
+                y = layer.forward_cm(y, pad8)
+            return y, pad8
         if L > self.max_seq_len:   # eval: table rebuilt on the fly (Models.py:145-152)
             pos = get_sinusoid_encoding_table(L, self.d_model)[:L, :].unsqueeze(0).to(enc_seq.device)
             x = enc_seq + pos
@@ -158,6 +195,8 @@ class Decoder(nn.Module):
         return y, pad8
 
     def forward(self, enc_seq, mask, return_attns=False):
+        if self.training:
+            return ag.transpose_to_blm(self.forward_cm(enc_seq, mask)[0])
         with torch.no_grad():
             y, _ = self.forward_cm(enc_seq, mask)
             return ops.transpose_bml(y, True)
@@ -201,9 +240,31 @@ class PostNet(nn.Module):
         conv.__dict__["_mg_folded"] = (key, wp, b)
         return wp, b
 
+    bn_group = None      # set to a torch.distributed process group for cross-rank BatchNorm statistics
+    dropout_p = 0.5      # F.dropout(..., 0.5, self.training), transformer/Layers.py:133-134
+
+    def _forward_cm_train(self, x):
+        n = len(self.convolutions)
+        k = self.kernel_size
+        for i in range(n):
+            conv, bn = self.convolutions[i][0].conv, self.convolutions[i][1]
+            h = ag.conv1d(x, conv.weight, conv.bias, 1, (k - 1) // 2)
+            keep, scale = _keep_mask(self, tuple(h.shape), self.dropout_p, h.device)
+            x, mean, var = ag.batchnorm_act(h, bn.weight, bn.bias, keep, scale, "tanh" if i < n - 1 else None, bn.eps,
+                                            self.bn_group)
+            with torch.no_grad():    # running statistics as nn.BatchNorm1d (momentum 0.1, unbiased variance)
+                cnt = h.shape[0] * h.shape[2] * (1 if self.bn_group is None
+                                                 else torch.distributed.get_world_size(self.bn_group))
+                m = bn.momentum
+                bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                bn.running_var.mul_(1 - m).add_(var * (cnt / max(cnt - 1, 1)), alpha=m)
+                bn.num_batches_tracked += 1
+        return x
+
     def forward_cm(self, x):
         """x [B, M, L] channel-major -> [B, M, L]."""
-        _require_eval(self)
+        if self.training:
+            return self._forward_cm_train(x)
         n = len(self.convolutions)
         k = self.kernel_size
         for i in range(n):
@@ -216,5 +277,7 @@ class PostNet(nn.Module):
         """x [B, L, M] -> [B, L, M] (transformer/Layers.py:129-137)."""
         if not x.is_cuda:
             raise _lib.MixganHipError("PostNet.forward on %s: the HIP path has no CPU fallback" % x.device)
+        if self.training:
+            return ag.transpose_to_blm(self.forward_cm(ag.transpose_to_bml(x)))
         with torch.no_grad():
             return ops.transpose_bml(self.forward_cm(ops.transpose_bml(x.detach().contiguous(), False)), True)

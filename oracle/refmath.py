@@ -301,8 +301,16 @@ def sinusoid_table(n_position, d_hid):
     return tab.float()
 
 
-def mha_forward(W, p, x, pad_mask, n_head=2):
-    """transformer/SubLayers.py:29-57 + Modules.py:16-23 (eval: dropout = identity).
+def _drop(x, p, drop):
+    """nn.Dropout(p) / F.dropout(p, training=True) with the keep-mask taken from `drop(shape, p)` (a tape in the
+    tests; None = eval / identity)."""
+    if drop is None or p <= 0:
+        return x
+    return x * drop(tuple(x.shape), p).to(x.dtype) / (1.0 - p)
+
+
+def mha_forward(W, p, x, pad_mask, n_head=2, drop=None, p_drop=0.2):
+    """transformer/SubLayers.py:29-57 + Modules.py:16-23 (drop=None: eval, dropout = identity).
 
     x [B,L,D]; pad_mask bool [B,L] True = pad (keys masked with -inf for every query row).
     """
@@ -315,26 +323,26 @@ def mha_forward(W, p, x, pad_mask, n_head=2):
     km = pad_mask.unsqueeze(1).expand(-1, L, -1).repeat(n_head, 1, 1)
     att = torch.softmax(att.masked_fill(km, float("-inf")), dim=2)
     o = torch.bmm(att, v).view(n_head, B, L, dk).permute(1, 2, 0, 3).reshape(B, L, D)
-    o = lin("fc", o)
+    o = _drop(lin("fc", o), p_drop, drop)
     return F.layer_norm(o + x, (D,), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], 1e-5)
 
 
-def ffn_forward(W, p, x):
-    """transformer/SubLayers.py:85-93 (eval)."""
+def ffn_forward(W, p, x, drop=None, p_drop=0.2):
+    """transformer/SubLayers.py:85-93."""
     D = x.shape[-1]
     k = W[p + "w_1.weight"].shape[-1]
     h = F.relu(F.conv1d(x.transpose(1, 2), W[p + "w_1.weight"], W[p + "w_1.bias"], padding=(k - 1) // 2))
-    o = F.conv1d(h, W[p + "w_2.weight"], W[p + "w_2.bias"]).transpose(1, 2)
+    o = _drop(F.conv1d(h, W[p + "w_2.weight"], W[p + "w_2.bias"]).transpose(1, 2), p_drop, drop)
     return F.layer_norm(o + x, (D,), W[p + "layer_norm.weight"], W[p + "layer_norm.bias"], 1e-5)
 
 
-def fft_block(W, p, x, pad_mask, n_head=2):
+def fft_block(W, p, x, pad_mask, n_head=2, drop=None, p_drop=0.2):
     """transformer/Layers.py:21-30."""
-    y = mha_forward(W, p + "slf_attn.", x, pad_mask, n_head).masked_fill(pad_mask.unsqueeze(-1), 0)
-    return ffn_forward(W, p + "pos_ffn.", y).masked_fill(pad_mask.unsqueeze(-1), 0)
+    y = mha_forward(W, p + "slf_attn.", x, pad_mask, n_head, drop, p_drop).masked_fill(pad_mask.unsqueeze(-1), 0)
+    return ffn_forward(W, p + "pos_ffn.", y, drop, p_drop).masked_fill(pad_mask.unsqueeze(-1), 0)
 
 
-def decoder_forward(W, p, x, pad_mask, max_seq_len, n_layers=6, n_head=2, training=False):
+def decoder_forward(W, p, x, pad_mask, max_seq_len, n_layers=6, n_head=2, training=False, drop=None, p_drop=0.2):
     """transformer/Models.py:139-171."""
     B, L, D = x.shape
     if (not training) and L > max_seq_len:
@@ -344,21 +352,25 @@ def decoder_forward(W, p, x, pad_mask, max_seq_len, n_layers=6, n_head=2, traini
         y = x[:, :L, :] + W[p + "position_enc"][:, :L, :]
         pad_mask = pad_mask[:, :L]
     for i in range(n_layers):
-        y = fft_block(W, p + "layer_stack.%d." % i, y, pad_mask, n_head)
+        y = fft_block(W, p + "layer_stack.%d." % i, y, pad_mask, n_head, drop if training else None, p_drop)
     return y
 
 
-def postnet_forward(W, p, x, n_conv=5):
-    """transformer/Layers.py:129-137 in eval mode (BatchNorm running stats, dropout off)."""
+def postnet_forward(W, p, x, n_conv=5, training=False, drop=None):
+    """transformer/Layers.py:129-137.  eval: BatchNorm running stats, dropout off.  training: batch statistics
+    (the running_mean / running_var entries of W are updated in place like nn.BatchNorm1d, momentum 0.1) and
+    F.dropout(., 0.5) after every layer with keep-masks from `drop`."""
     y = x.transpose(1, 2)
     for i in range(n_conv):
         c = p + "convolutions.%d." % i
         k = W[c + "0.conv.weight"].shape[-1]
         y = F.conv1d(y, W[c + "0.conv.weight"], W[c + "0.conv.bias"], padding=(k - 1) // 2)
         y = F.batch_norm(y, W[c + "1.running_mean"], W[c + "1.running_var"], W[c + "1.weight"], W[c + "1.bias"],
-                         False, 0.1, 1e-5)
+                         training, 0.1, 1e-5)
         if i < n_conv - 1:
             y = torch.tanh(y)
+        if training:
+            y = _drop(y, 0.5, drop)
     return y.transpose(1, 2)
 
 

@@ -528,6 +528,106 @@ def main():
     _dump("text_dev", [ref_to_device(b3, torch.device("cpu"))])
     save("dataset", **arrs)
 
+    # (f4) aux pre-training: train-mode FFTBlock / Decoder / PostNet (dropout masks taped) + ScheduledOptim -----
+    print("aux_train")
+    import torch.nn.functional as _F
+    from model.optimizer import ScheduledOptim as RefScheduledOptim
+    arng = np.random.default_rng(777001)
+
+    class DropTape:
+        def __init__(self):
+            self.masks = []
+
+        def __call__(self, x, p=0.5, training=True, inplace=False):
+            if not training or p == 0.0:
+                return x
+            keep = torch.from_numpy((arng.random(tuple(x.shape)) >= p).astype(np.float32))
+            self.masks.append(keep.numpy().astype(np.uint8))
+            return x * keep / (1.0 - p)
+
+    def taped(fn):
+        tape, saved = DropTape(), _F.dropout
+        _F.dropout = tape
+        try:
+            out = fn()
+        finally:
+            _F.dropout = saved
+        return out, tape.masks
+
+    def draw(shape):
+        return torch.from_numpy(arng.standard_normal(shape).astype(np.float32))
+
+    arrs = {}
+    # FFTBlock, train mode
+    blk = FFTBlock(256, 2, 128, 128, 1024, 9, dropout=0.2).train()
+    seed_module(blk, 51, "fftblock")
+    B, L = 2, 37
+    pad = torch.arange(L)[None, :] >= torch.tensor([37, 22])[:, None]
+    x = draw((B, L, 256)).requires_grad_()
+    go = draw((B, L, 256))
+    (y, _), masks = taped(lambda: blk(x, mask=pad, slf_attn_mask=pad.unsqueeze(1).expand(-1, L, -1)))
+    (y * go).sum().backward()
+    arrs.update({"fft/x": x, "fft/pad": pad, "fft/go": go, "fft/out": y, "fft/d_x": x.grad})
+    for i_, m_ in enumerate(masks):
+        arrs["fft/mask%d" % i_] = m_
+    for k, p in blk.named_parameters():
+        dg, corner = grad_digest(p.grad)
+        arrs["fft/dw_sum/" + k] = dg
+        arrs["fft/dw_corner/" + k] = corner
+    # Decoder, train mode, input longer than max_seq_len (Models.py:153-162 clips it)
+    _, pre, mc, _ = configs("shallow", 4, stats_dir=stats, max_seq_len=48)
+    dec = Decoder(mc).train()
+    seed_module(dec, 52, "decoder")
+    Ld = 53
+    padd = torch.arange(Ld)[None, :] >= torch.tensor([53, 40])[:, None]
+    xd = draw((2, Ld, 256)).requires_grad_()
+    yd, masks = taped(lambda: dec(xd, padd))
+    god = draw(tuple(yd.shape))
+    (yd * god).sum().backward()
+    arrs.update({"dec/x": xd, "dec/pad": padd, "dec/go": god, "dec/out": yd, "dec/d_x": xd.grad,
+                 "dec/max_seq_len": 48})
+    for i_, m_ in enumerate(masks):
+        arrs["dec/mask%d" % i_] = m_
+    for k, p in dec.named_parameters():
+        if p.grad is not None:
+            arrs["dec/dw_sum/" + k] = grad_digest(p.grad)[0]
+    # PostNet, train mode (BatchNorm batch statistics, dropout 0.5)
+    pn = PostNet().train()
+    seed_module(pn, 53, "postnet")
+    xp = draw((3, 45, M)).requires_grad_()
+    yp, masks = taped(lambda: pn(xp))
+    gop = draw(tuple(yp.shape))
+    (yp * gop).sum().backward()
+    arrs.update({"pn/x": xp, "pn/go": gop, "pn/out": yp, "pn/d_x": xp.grad})
+    for i_, m_ in enumerate(masks):
+        arrs["pn/mask%d" % i_] = m_
+    for k, p in pn.named_parameters():
+        dg, corner = grad_digest(p.grad)
+        arrs["pn/dw_sum/" + k] = dg
+        arrs["pn/dw_corner/" + k] = corner
+    for k, b_ in pn.named_buffers():
+        arrs["pn/buf/" + k] = b_.detach().numpy().copy()
+    # ScheduledOptim (model/optimizer.py:5-56): lr after each of the first steps and across the anneal boundary
+    tcfg = {"optimizer_fs2": {"betas": [0.9, 0.98], "eps": 1e-9, "weight_decay": 0.0, "warm_up_step": 5,
+                              "anneal_steps": [8, 11], "anneal_rate": 0.3}}
+    lin = torch.nn.Linear(3, 2)
+    with torch.no_grad():
+        lin.weight.copy_(draw((2, 3)))
+        lin.bias.copy_(draw((2,)))
+    arrs["so/w0"], arrs["so/b0"] = lin.weight.detach().numpy().copy(), lin.bias.detach().numpy().copy()
+    so = RefScheduledOptim(lin, tcfg, {"transformer": {"encoder_hidden": 256}}, 2)
+    xin = draw((4, 3))
+    arrs["so/x"] = xin
+    lrs = []
+    for _ in range(12):
+        so.zero_grad()
+        lin(xin).pow(2).sum().backward()
+        lrs.append(so.step())
+    arrs["so/lrs"] = np.array(lrs, dtype=np.float64)
+    arrs["so/w_end"], arrs["so/b_end"] = lin.weight.detach().numpy().copy(), lin.bias.detach().numpy().copy()
+    arrs["so/init_lr"] = np.array(so.init_lr)
+    save("aux_train", **arrs)
+
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(MANIFEST, f, indent=0, sort_keys=True)
     print("manifest written")

@@ -32,8 +32,6 @@ def test_fftblock_golden(mg, manifest):
     blk = blk.cuda().eval()
     y, _ = blk(dev(g["x"]), mask=dev(g["pad"]))
     assert_close(y.cpu(), g["out"], TOL, "FFTBlock")
-    with pytest.raises(NotImplementedError):
-        blk.train()(dev(g["x"]), mask=dev(g["pad"]))
 
 
 def test_decoder_and_postnet_golden(mg, manifest):

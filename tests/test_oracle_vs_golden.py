@@ -234,3 +234,84 @@ def test_hifigan_generator(manifest):
     y = R.hifigan_forward(W, T(g["mel"]))
     assert tuple(y.shape) == (2, 1, 13 * 256)
     assert_close(y, g["wav"], 1e-5, "hifigan")
+
+
+class _MaskTape:
+    """drop(shape, p) stand-in replaying the reference's dropout keep-masks in call order."""
+
+    def __init__(self, g, prefix):
+        self.masks = [T(g[k]) for k in sorted((k for k in g if k.startswith(prefix + "/mask")),
+                                              key=lambda k: int(k.rsplit("mask", 1)[1]))]
+        self.i = 0
+
+    def __call__(self, shape, p):
+        m = self.masks[self.i]
+        self.i += 1
+        assert tuple(m.shape) == tuple(shape)
+        return m
+
+
+def test_aux_train_mode_blocks(manifest):
+    """train-mode FFTBlock / Decoder / PostNet of the oracle (dropout masks replayed,
+    BatchNorm batch statistics) against a reference run, forward and backward."""
+    g = golden("aux_train")
+    # FFTBlock
+    W, _ = seeded(manifest, "fftblock", 51, requires_grad=True)
+    x = T(g["fft/x"]).requires_grad_()
+    tape = _MaskTape(g, "fft")
+    y = R.fft_block(W, "", x, T(g["fft/pad"]), drop=tape)
+    assert tape.i == len(tape.masks) == 2
+    assert_close(y, g["fft/out"], 2e-6, "fft train out")
+    (y * T(g["fft/go"])).sum().backward()
+    assert_close(x.grad, g["fft/d_x"], 2e-5, "fft train d_x")
+    for k in W:
+        assert_digest(W[k].grad, {kk[4:]: v for kk, v in g.items() if kk.startswith("fft/dw")}, k, 2e-5)
+    # Decoder (input longer than max_seq_len: clipped in train mode)
+    W, _ = seeded(manifest, "decoder", 52, requires_grad=True)
+    msl = int(g["dec/max_seq_len"])
+    W["position_enc"] = R.sinusoid_table(msl + 1, 256)[None]
+    x = T(g["dec/x"]).requires_grad_()
+    tape = _MaskTape(g, "dec")
+    y = R.decoder_forward(W, "", x, T(g["dec/pad"]), msl, training=True, drop=tape)
+    assert tape.i == 12 and tuple(y.shape) == (2, msl, 256)
+    assert_close(y, g["dec/out"], 1e-5, "decoder train out")
+    (y * T(g["dec/go"])).sum().backward()
+    assert_close(x.grad, g["dec/d_x"], 5e-5, "decoder train d_x")
+    # PostNet
+    W, _ = seeded(manifest, "postnet", 53, requires_grad=True)
+    x = T(g["pn/x"]).requires_grad_()
+    tape = _MaskTape(g, "pn")
+    y = R.postnet_forward(W, "", x, training=True, drop=tape)
+    assert tape.i == 5
+    assert_close(y, g["pn/out"], 5e-6, "postnet train out")
+    (y * T(g["pn/go"])).sum().backward()
+    assert_close(x.grad, g["pn/d_x"], 5e-5, "postnet train d_x")
+    for k in W:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert_close(W[k], g["pn/buf/" + k], 1e-6, k)
+        elif not k.endswith("num_batches_tracked"):
+            assert_digest(W[k].grad, {kk[3:]: v for kk, v in g.items() if kk.startswith("pn/dw")}, k, 5e-5)
+
+
+def test_scheduled_optim_matches_reference():
+    """model/optimizer.py:5-56: lr sequence across warm-up and two anneal boundaries, and the weights after 12
+    Adam steps (CPU)."""
+    import mixgan_tts_amd as mg
+    g = golden("aux_train")
+    tcfg = {"optimizer_fs2": {"betas": [0.9, 0.98], "eps": 1e-9, "weight_decay": 0.0, "warm_up_step": 5,
+                              "anneal_steps": [8, 11], "anneal_rate": 0.3}}
+    lin = torch.nn.Linear(3, 2)
+    with torch.no_grad():
+        lin.weight.copy_(T(g["so/w0"]))
+        lin.bias.copy_(T(g["so/b0"]))
+    so = mg.ScheduledOptim(lin, tcfg, {"transformer": {"encoder_hidden": 256}}, 2)
+    assert so.init_lr == float(g["so/init_lr"]) == so.get_last_lr()
+    lrs = []
+    for _ in range(12):
+        so.zero_grad()
+        lin(T(g["so/x"])).pow(2).sum().backward()
+        lrs.append(so.step())
+    np.testing.assert_allclose(np.array(lrs), g["so/lrs"], rtol=1e-15)
+    assert so.get_last_lr() == lrs[-1]
+    assert_close(lin.weight, g["so/w_end"], 1e-6, "ScheduledOptim weights")
+    assert_close(lin.bias, g["so/b_end"], 1e-6, "ScheduledOptim bias")
