@@ -238,6 +238,13 @@ int mg_linear_small_fwd(const float *x, const float *W, float *out, int B, int N
 int mg_linear_small_bwd(const float *g, const float *x, const float *W, float *dx, float *dW, int B,
                         int N, int K, void *stream);
 
+/* Gradient of diffuse_trace (model/diffusion.py:167-175) w.r.t. x_start [B,L,M]: g is the stack [T+1,B,L,M] of the
+ * gradients of the T+1 trace entries (entry 0 = clamped normalised x_start, entry t+1 = q_sample at step t); keep
+ * uint8 [B,L] (0 = padded frame) or NULL; sqrt_alphas_cumprod [T]. */
+int mg_diffuse_trace_bwd(const float *g, const float *x_start, const float *spec_min, const float *spec_max,
+                         const uint8_t *keep, const float *sqrt_alphas_cumprod, float *d_x, int T, int B, int L, int M,
+                         void *stream);
+
 /* ------------------------------------------------------------------ aux pre-training
  * Strided batched fp32 GEMM on the MFMA: C[z](m,n) (+)= alpha * sum_k A[z](m,k) B[z](k,n), z = b*heads + h,
  * operand z at base + b*x_bs + h*x_hs; A(m,k) at m*a_ms + k*a_ks, B(k,n) at k*b_ks + n*b_ns (one stride of each

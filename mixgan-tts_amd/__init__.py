@@ -14,7 +14,7 @@ from .denoiser import Denoiser  # noqa: F401
 from .diffusion import GaussianDiffusion  # noqa: F401
 from .discriminator import JCUDiscriminator  # noqa: F401
 from . import ops, autograd, losses, distributed  # noqa: F401
-from .train_step import HotPathTrainer  # noqa: F401
+from .train_step import HotPathTrainer, AuxTrainer  # noqa: F401
 from . import lingops, vocoder, data  # noqa: F401
 from .optimizer import ScheduledOptim  # noqa: F401
 from .mixgantts import MixGANTTS, get_mask_from_lengths  # noqa: F401

@@ -256,6 +256,43 @@ extern "C" int mg_spec_affine(const float *in, float *out, const float *spec_min
 }
 
 // ---------------------------------------------------------------------------------------------
+// gradient of diffuse_trace (model/diffusion.py:167-175) w.r.t. x_start [B, L, M]:
+//   trace[0]   = clamp(norm(x), -1, 1) * keep            -> slope_m * keep * 1[|norm(x)| <= 1]
+//   trace[t+1] = (sqrt_ac[t] norm(x) + sqrt(1-ac[t]) eps) * keep -> slope_m * keep * sqrt_ac[t]
+// g: [T+1, B, L, M] stacked output gradients; slope_m = 2 / (spec_max[m] - spec_min[m]).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void diffuse_trace_bwd_kernel(const float *__restrict__ g, const float *__restrict__ x,
+                                                                const float *__restrict__ spec_min,
+                                                                const float *__restrict__ spec_max,
+                                                                const uint8_t *__restrict__ keep,
+                                                                const float *__restrict__ sqrt_ac, float *__restrict__ dx,
+                                                                int T, size_t n, int M)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i % M);
+        const float mn = spec_min[m], mx = spec_max[m];
+        const float nv = norm1(x[i], mn, mx);
+        float a = fabsf(nv) <= 1.f ? g[i] : 0.f;
+        for (int t = 0; t < T; ++t) a = fmaf(sqrt_ac[t], g[(size_t)(t + 1) * n + i], a);
+        dx[i] = (keep && !keep[i / M]) ? 0.f : a * 2.f / (mx - mn);
+    }
+}
+
+extern "C" int mg_diffuse_trace_bwd(const float *g, const float *x_start, const float *spec_min, const float *spec_max,
+                                    const uint8_t *keep, const float *sqrt_alphas_cumprod, float *d_x, int T, int B, int L,
+                                    int M, void *stream)
+{
+    if (!g || !x_start || !spec_min || !spec_max || !sqrt_alphas_cumprod || !d_x) return MG_ERR_ARG;
+    if (T < 0 || B <= 0 || L <= 0 || M <= 0) return MG_ERR_SHAPE;
+    const size_t n = (size_t)B * L * M;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(diffuse_trace_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, x_start, spec_min,
+                       spec_max, keep, sqrt_alphas_cumprod, d_x, T, n, M);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // gradient of mg_posterior_sample_fwd w.r.t. x0 (the only differentiable input on the path)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void posterior_bwd_kernel(const float *__restrict__ x0,

@@ -193,7 +193,13 @@ class GaussianDiffusion(nn.Module):
         return g["x"][g["final"]].clone()
 
     def diffuse_trace(self, x_start, mask):
-        """aux only (model/diffusion.py:167-175): mask True = pad."""
+        """aux only (model/diffusion.py:167-175): mask True = pad.  Differentiable w.r.t. x_start (the coarse mel
+        of aux pre-training): the T+1 entries come out of one autograd node whose backward is mg_diffuse_trace_bwd."""
+        if torch.is_grad_enabled() and x_start.requires_grad:
+            return list(_DiffuseTraceFn.apply(self, x_start, mask))
+        return self._diffuse_trace(x_start, mask)
+
+    def _diffuse_trace(self, x_start, mask):
         B, L, M = x_start.shape
         keep = (~mask).to(torch.uint8).contiguous()
         first = self.norm_spec(x_start).clamp_(-1.0, 1.0) * (~mask).unsqueeze(-1)
@@ -256,3 +262,27 @@ class GaussianDiffusion(nn.Module):
             _, x0c = ops.posterior_sample(x0, x_t_b, t, post_noise, keep, buf, clip=clip_denoised, want_x0c=True)
         tb = lambda a: ops.transpose_bml(a, True)
         return tb(x0c), tb(x_t_b), tb(x_prev_b), tb(xpp), t
+
+
+class _DiffuseTraceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, diff, x_start, mask):
+        x = x_start.detach().contiguous()
+        trace = diff._diffuse_trace(x, mask)
+        ctx.diff = diff
+        ctx.save_for_backward(x, (~mask).to(torch.uint8).contiguous())
+        return tuple(trace)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        x, keep = ctx.saved_tensors
+        diff = ctx.diff
+        B, L, M = x.shape
+        T = diff.num_timesteps
+        g = torch.stack([gi if gi is not None else torch.zeros_like(x) for gi in gs]).contiguous()
+        dx = torch.empty_like(x)
+        _lib.check(_lib.lib().mg_diffuse_trace_bwd(
+            _lib.fptr(g), _lib.fptr(x), _lib.fptr(diff.spec_min.contiguous()), _lib.fptr(diff.spec_max.contiguous()),
+            _lib.iptr(keep, torch.uint8), _lib.fptr(diff._buf()["sqrt_alphas_cumprod"].contiguous()), _lib.fptr(dx),
+            T, B, L, M, _lib.stream_ptr()))
+        return None, dx, None

@@ -55,7 +55,13 @@ class MixGANTTS(nn.Module):
         return p.detach() if p is not None and self.model == "shallow" else p
 
     def coarse_mel(self, cond, mel_pad_mask):
-        """Decoder -> mel_linear -> PostNet residual (model/mixgantts.py:140-143), channel-major inside."""
+        """Decoder -> mel_linear -> PostNet residual (model/mixgantts.py:140-143), channel-major inside.
+        In train mode with grad enabled (aux pre-training) every step is a differentiable HIP Function."""
+        if self.training and torch.is_grad_enabled():
+            from . import autograd as ag
+            y, _ = self.decoder.forward_cm(cond, mel_pad_mask)
+            m = ag.conv1d(y, self.mel_linear.weight[:, :, None], self.mel_linear.bias)
+            return ag.transpose_to_blm(self.postnet.forward_cm(m) + m)
         y, pad8 = self.decoder.forward_cm(cond, mel_pad_mask)
         M = self.mel_linear.weight.shape[0]
         m = ops.conv1d_packed(y, ops.pack_cached(self.mel_linear.weight[:, :, None]), self.mel_linear.bias.detach(), M, 1)
@@ -89,8 +95,11 @@ class MixGANTTS(nn.Module):
             output, x_ts, x_t_prevs, x_t_prev_preds, diffusion_step = self.diffusion(mels, output, speaker_emb, mel_masks)
         elif self.model in ["aux", "shallow"]:
             cond = output.clone()
-            with torch.no_grad():                    # eval-mode FFT path (train mode raises inside)
-                coarse_mels = self.coarse_mel(output, mel_masks)
+            if self.model == "aux" and self.training and torch.is_grad_enabled():
+                coarse_mels = self.coarse_mel(output, mel_masks)          # differentiable (aux pre-training)
+            else:
+                with torch.no_grad():
+                    coarse_mels = self.coarse_mel(output, mel_masks)
             postnet_outputs = coarse_mels
             if self.model == "aux":
                 output = self.diffusion.diffuse_trace(coarse_mels, mel_masks)

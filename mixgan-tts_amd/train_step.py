@@ -74,3 +74,46 @@ class HotPathTrainer:
     def end_epoch(self):
         self.sdlG.step()
         self.sdlD.step()
+
+
+class AuxTrainer:
+    """The `--model aux` step of train.py:97-128 for the modules on the HIP path: coarse mel (Decoder ->
+    mel_linear -> PostNet, train mode) -> diffuse_trace -> acoustic reconstruction loss (model/loss.py:153-161:
+    mae(postnet_output, mel) + sum_t masked-L1(denorm(trace_t), mel)) -> backward -> gradient all-reduce ->
+    clip_grad_norm_ -> ScheduledOptim (model/optimizer.py).  The linguistic encoder's own loss terms
+    (duration / pitch / energy / alignment helper, out of scope) enter through `extra_loss`.
+
+    model: a module with `.coarse_mel(cond, pad_mask)` and `.diffusion` (mixgan_tts_amd.MixGANTTS built with
+    args.model == "aux"); `params` defaults to model.parameters() (include the linguistic encoder's there)."""
+
+    def __init__(self, model, train_config, model_config, current_step=0, params=None):
+        from .optimizer import ScheduledOptim
+        self.model = model
+        self.params = [p for p in (params if params is not None else model.parameters()) if p.requires_grad]
+        holder = type("_P", (), {"parameters": lambda s: iter(self.params)})()
+        self.opt = ScheduledOptim(holder, train_config, model_config, current_step)
+        self.grad_clip = train_config["optimizer"]["grad_clip_thresh"]
+        self.bucket = GradBucket(self.params)
+
+    def acoustic_losses(self, cond, mel_targets, mel_pad_mask):
+        m = self.model
+        coarse = m.coarse_mel(cond, mel_pad_mask)
+        Lc = coarse.shape[1]
+        pad, target = mel_pad_mask[:, :Lc], mel_targets[:, :Lc, :].contiguous()
+        trace = m.diffusion.diffuse_trace(coarse, pad)
+        mel_loss = 0
+        for tr in trace:
+            mel_loss = mel_loss + losses.get_mel_loss(m.diffusion.denorm_spec(tr), target, pad)
+        return mel_loss, losses._L1Fn.apply(coarse, target), coarse
+
+    def step(self, cond, mel_targets, mel_pad_mask, extra_loss=None):
+        mel_loss, postnet_loss, _ = self.acoustic_losses(cond, mel_targets, mel_pad_mask)
+        loss = mel_loss + postnet_loss
+        if extra_loss is not None:
+            loss = loss + extra_loss
+        loss.backward()
+        self.bucket.all_reduce_mean()
+        torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
+        lr = self.opt.step()
+        self.opt.zero_grad()
+        return {"mel_loss": mel_loss.detach(), "postnet_loss": postnet_loss.detach(), "lr": lr}

@@ -374,11 +374,22 @@ def postnet_forward(W, p, x, n_conv=5, training=False, drop=None):
     return y.transpose(1, 2)
 
 
-def coarse_mel(W, x, pad_mask, max_seq_len, n_layers=6, n_head=2):
+def coarse_mel(W, x, pad_mask, max_seq_len, n_layers=6, n_head=2, training=False, drop=None):
     """model/mixgantts.py:140-143: Decoder -> mel_linear -> PostNet residual."""
-    h = decoder_forward(W, "decoder.", x, pad_mask, max_seq_len, n_layers, n_head)
+    h = decoder_forward(W, "decoder.", x, pad_mask, max_seq_len, n_layers, n_head, training, drop)
     m = F.linear(h, W["mel_linear.weight"], W["mel_linear.bias"])
-    return postnet_forward(W, "postnet.", m) + m
+    return postnet_forward(W, "postnet.", m, training=training, drop=drop) + m
+
+
+def aux_acoustic_losses(W, buf, x, mel_targets, pad_mask, max_seq_len, T, tape, drop):
+    """The acoustic part of the aux-mode loss (model/loss.py:153-161): mae(postnet_output, mel) + sum over the
+    diffuse_trace entries of the masked mel L1; returns (mel_loss, postnet_loss, coarse)."""
+    coarse = coarse_mel(W, x, pad_mask, max_seq_len, training=True, drop=drop)
+    pad = pad_mask[:, :coarse.shape[1]]
+    target = mel_targets[:, :coarse.shape[1], :]
+    trace = diffuse_trace(buf, coarse, pad, T, tape)
+    mel_loss = sum(mel_l1(denorm_spec(tr, buf["spec_min"], buf["spec_max"]), target, pad) for tr in trace)
+    return mel_loss, F.l1_loss(coarse, target), coarse
 
 
 # ----------------------------------------------------------------------------- linguistic-encoder index ops

@@ -205,3 +205,80 @@ def test_postnet_train_golden(mg, manifest, tape_hook):
     # eval after training uses the updated running statistics (folded-BN cache must notice)
     pn.eval()
     assert torch.isfinite(pn(x.detach())).all()
+
+
+def test_aux_trainer_step_vs_oracle(mg, manifest, tmp_path):
+    """One `--model aux` step (train.py:97-128) on the HIP path: losses, the gradient reaching the linguistic
+    encoder's output, parameter gradients and the ScheduledOptim update against the oracle chain + torch Adam."""
+    from helpers import write_stats, seeded, Tape
+    from oracle import refmath as R, schedule as S
+    e = golden("elementwise")
+    stats = write_stats(tmp_path, e["spec_min"], e["spec_max"])
+    args, pre, mc, tr = hot_path_configs("aux", 4, stats_dir=stats, max_seq_len=64)
+    tr = dict(tr)
+    tr["optimizer_fs2"] = {"betas": [0.9, 0.98], "eps": 1e-9, "weight_decay": 0.0, "warm_up_step": 4000,
+                           "anneal_steps": [300000], "anneal_rate": 0.3}
+    tr.setdefault("optimizer", {})["grad_clip_thresh"] = 1.0
+    gen = torch.Generator().manual_seed(5)
+    B, L = 2, 50
+    cond = torch.randn(B, L, 256, generator=gen)
+    mel = torch.rand(B, L, 80, generator=gen) * 8 - 9
+    pad = torch.arange(L)[None, :] >= torch.tensor([50, 36])[:, None]
+    net = mg.MixGANTTS(args, pre, mc, tr)
+    W = {}
+    for name, mod, seed, pfx in (("decoder", net.decoder, 71, "decoder."), ("postnet", net.postnet, 72, "postnet.")):
+        load_seeded(mod, manifest, name, seed)
+        w, _ = seeded(manifest, name, seed, prefix=pfx, requires_grad=True)
+        W.update(w)
+    W["decoder.position_enc"] = R.sinusoid_table(65, 256)[None]
+    with torch.no_grad():
+        net.mel_linear.weight.copy_(torch.randn(80, 256, generator=gen) / 16)
+        net.mel_linear.bias.copy_(torch.randn(80, generator=gen) * 0.1)
+    W["mel_linear.weight"] = net.mel_linear.weight.detach().clone().requires_grad_()
+    W["mel_linear.bias"] = net.mel_linear.bias.detach().clone().requires_grad_()
+    net = net.cuda().train()
+    # dropout masks (12 in the decoder on [B,L,256], 5 in the PostNet on [B,C,L]) and the 4 q_sample noises
+    masks = [(torch.rand(B, L, 256, generator=gen) >= 0.2) for _ in range(12)]
+    pmasks = [(torch.rand(B, c, L, generator=gen) >= 0.5) for c in (512, 512, 512, 512, 80)]
+    noises = [torch.randn(B, 1, 80, L, generator=gen) for _ in range(4)]
+
+    seq_o = iter([m.float() for m in masks] + [m.float() for m in pmasks])
+    seq_g = iter([m.transpose(1, 2).contiguous() for m in masks] + pmasks)
+    mg.transformer.DROPOUT_FN = lambda shape, p, device: next(seq_g).to(torch.uint8).to(device)
+    try:
+        net.diffusion.noise_fn = Tape([n.numpy() for n in noises])
+        params = [p for n_, p in net.named_parameters() if n_.split(".")[0] in ("decoder", "mel_linear", "postnet")
+                  and p.requires_grad]
+        trainer = mg.AuxTrainer(net, tr, mc, current_step=0, params=params)
+        cg = cond.cuda().requires_grad_()
+        mel_loss, post_loss, coarse = trainer.acoustic_losses(cg, mel.cuda(), pad.cuda())
+        (mel_loss + post_loss).backward()
+    finally:
+        mg.transformer.DROPOUT_FN = None
+    buf = {k: T(v) for k, v in S.diffusion_buffers(S.beta_schedule("vpsde", 4, 0.1, 40, 0.008)).items()}
+    buf["spec_min"], buf["spec_max"] = T(e["spec_min"])[None, None], T(e["spec_max"])[None, None]
+    co = cond.clone().requires_grad_()
+    ml_o, pl_o, coarse_o = R.aux_acoustic_losses(W, buf, co, mel, pad, 64, 4, R.NoiseTape(noises),
+                                                 lambda shape, p: next(seq_o))
+    (ml_o + pl_o).backward()
+    assert_close(coarse.detach().cpu(), coarse_o.detach(), TOL, "aux coarse mel (train mode)")
+    assert abs(mel_loss.item() - ml_o.item()) <= TOL * abs(ml_o.item())
+    assert abs(post_loss.item() - pl_o.item()) <= TOL * abs(pl_o.item())
+    assert_close(cg.grad.cpu(), co.grad, TOL, "d loss / d encoder output")
+    named = dict(net.named_parameters())
+    for k, w in W.items():
+        if w.requires_grad and w.grad is not None and not (k.endswith("w_ks.bias") or k.endswith("conv.bias")):
+            gref = w.grad.double()
+            got = named[k].grad.double().cpu()
+            scale = gref.abs().sum().item() + 1e-30
+            assert (got - gref).abs().sum().item() <= 2 * TOL * scale, k
+    # optimizer: the clipped-gradient ScheduledOptim update equals torch Adam on the oracle gradients
+    before = {k: named[k].detach().clone() for k in ("mel_linear.weight", "decoder.layer_stack.0.slf_attn.fc.weight")}
+    torch.nn.utils.clip_grad_norm_(params, 1.0)
+    lr = trainer.opt.step()
+    assert lr == pytest.approx(256 ** -0.5 * 4000 ** -1.5)
+    for k, b in before.items():
+        assert not torch.equal(b, named[k].detach())
+        # first Adam step moves every element by ~lr (sign of the gradient)
+        step = (named[k].detach() - b).abs().max().item()
+        assert step <= lr * 1.001 + 1e-7 * max(1.0, b.abs().max().item())   # + fp32 rounding of the weight
