@@ -263,7 +263,8 @@ int mg_softmax_rows_bwd(const float *P, float *dP, int B, int H, int L, float sc
 int mg_layernorm_cm_train_fwd(const float *a, const uint8_t *keep, float drop_scale, const float *res,
                               const float *gamma, const float *beta, const uint8_t *pad, float *pre, float *out, int B,
                               int C, int L, float eps, void *stream);
-/* d_pre (= d res), d_a = d_pre * keep * drop_scale (optional), dgamma / dbeta [C] ACCUMULATED (atomics). */
+/* d_pre (= d res), d_a = d_pre * keep * drop_scale (optional); dgamma / dbeta are [32][C] partial sums ACCUMULATED
+ * by atomics (the caller zeroes them and sums the 32 rows). */
 int mg_layernorm_cm_bwd(const float *pre, const float *dy, const float *gamma, const uint8_t *pad, const uint8_t *keep,
                         float drop_scale, float *d_pre, float *d_a, float *dgamma, float *dbeta, int B, int C, int L,
                         float eps, void *stream);

@@ -14,7 +14,8 @@
 // mg_bgemm: C[z][m][n] (+)= alpha * sum_k A[z](m,k) B[z](k,n), z = (b, h) with separate batch / head strides,
 // arbitrary element strides for A and B (one of the two strides of each operand must be 1), C row-major.
 // Workgroup tile 128 x 128 x 16, 4 waves as 2 x 2, wave tile 64 x 64 = 2 x 2 accumulators of
-// v_mfma_f32_32x32x2_f32; operand tiles are staged k-major in LDS ([16][129]) through registers with the next
+// v_mfma_f32_32x32x2_f32 (64 x 64 / 1 x 1 when that under-fills the chip); operand tiles are staged k-major in
+// LDS ([16][tile + 1]) through registers with the next
 // tile's global loads in flight behind the current tile's 32 MFMAs per wave.
 #include "common.h"
 
@@ -29,53 +30,63 @@ struct BgemmArgs {
     int accumulate;
 };
 
-#define BG_BM 128
 #define BG_BK 16
-#define BG_RS 129
 
-// MC: the M (resp. N) index is the contiguous one in memory, otherwise K is.
-template <bool A_MC, bool B_NC>
+// MC / NC: the M (resp. N) index is the contiguous one in memory, otherwise K is.
+// TI x TJ accumulators per wave: workgroup tile (64 TI) x (64 TJ); the 64 x 64 tile is used when the 128 x 128
+// one would leave the chip under-filled (the d = 128 row contractions O / dV / dQ / dK have M = 128).
+template <bool A_MC, bool B_NC, int TI, int TJ>
 __global__ __launch_bounds__(256, 2) void bgemm_kernel(BgemmArgs a)
 {
-    __shared__ float As[2][BG_BK * BG_RS];
-    __shared__ float Bs[2][BG_BK * BG_RS];
+    constexpr int TM = 64 * TI, TN = 64 * TJ, RSA = TM + 1, RSB = TN + 1;
+    constexpr int NA = TM * BG_BK / 256, NB = TN * BG_BK / 256;
+    __shared__ float As[2][BG_BK * RSA];
+    __shared__ float Bs[2][BG_BK * RSB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, hh = lane >> 5, r = lane & 31;
-    const int m0 = blockIdx.y * BG_BM, n0 = blockIdx.x * BG_BM;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
     const int zb = blockIdx.z / a.H, zh = blockIdx.z - zb * a.H;
     const float *A = a.A + (size_t)zb * a.a_bs + (size_t)zh * a.a_hs;
     const float *B = a.B + (size_t)zb * a.b_bs + (size_t)zh * a.b_hs;
     float *C = a.C + (size_t)zb * a.c_bs + (size_t)zh * a.c_hs;
 
-    float ra[8], rb[8];
+    float ra[NA], rb[NB];
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const int idx = tid + i * 256;
-            const int am = A_MC ? (idx & 127) : (idx >> 4), ak = A_MC ? (idx >> 7) : (idx & 15);
-            const int bn = B_NC ? (idx & 127) : (idx >> 4), bk = B_NC ? (idx >> 7) : (idx & 15);
-            const int gm = min(m0 + am, a.M - 1), gn = min(n0 + bn, a.N - 1);
-            const int gka = min(kt * BG_BK + ak, a.K - 1), gkb = min(kt * BG_BK + bk, a.K - 1);
+            const int am = A_MC ? (idx % TM) : (idx >> 4), ak = A_MC ? (idx / TM) : (idx & 15);
+            const int gm = min(m0 + am, a.M - 1), gka = min(kt * BG_BK + ak, a.K - 1);
             ra[i] = A[(size_t)gm * a.a_ms + (size_t)gka * a.a_ks];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + i * 256;
+            const int bn = B_NC ? (idx % TN) : (idx >> 4), bk = B_NC ? (idx / TN) : (idx & 15);
+            const int gn = min(n0 + bn, a.N - 1), gkb = min(kt * BG_BK + bk, a.K - 1);
             rb[i] = B[(size_t)gkb * a.b_ks + (size_t)gn * a.b_ns];
         }
     };
     auto sstore = [&](int buf, int kt) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const int idx = tid + i * 256;
-            const int am = A_MC ? (idx & 127) : (idx >> 4), ak = A_MC ? (idx >> 7) : (idx & 15);
-            const int bn = B_NC ? (idx & 127) : (idx >> 4), bk = B_NC ? (idx >> 7) : (idx & 15);
-            As[buf][ak * BG_RS + am] = (m0 + am < a.M && kt * BG_BK + ak < a.K) ? ra[i] : 0.f;
-            Bs[buf][bk * BG_RS + bn] = (n0 + bn < a.N && kt * BG_BK + bk < a.K) ? rb[i] : 0.f;
+            const int am = A_MC ? (idx % TM) : (idx >> 4), ak = A_MC ? (idx / TM) : (idx & 15);
+            As[buf][ak * RSA + am] = (m0 + am < a.M && kt * BG_BK + ak < a.K) ? ra[i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int idx = tid + i * 256;
+            const int bn = B_NC ? (idx % TN) : (idx >> 4), bk = B_NC ? (idx / TN) : (idx & 15);
+            Bs[buf][bk * RSB + bn] = (n0 + bn < a.N && kt * BG_BK + bk < a.K) ? rb[i] : 0.f;
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -86,36 +97,40 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(BgemmArgs a)
     for (int kt = 0; kt < nk; ++kt) {
         const int ktn = kt + 1 < nk ? kt + 1 : kt;
         gload(ktn);
-        const float *Ac = As[kt & 1] + wm * 64 + r, *Bc = Bs[kt & 1] + wn * 64 + r;
+        const float *Ac = As[kt & 1] + wm * 32 * TI + r, *Bc = Bs[kt & 1] + wn * 32 * TJ + r;
 #pragma unroll
         for (int s = 0; s < BG_BK / 2; ++s) {
-            const int ko = (2 * s + hh) * BG_RS;
-            const float a0 = Ac[ko], a1 = Ac[ko + 32], b0 = Bc[ko], b1 = Bc[ko + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float av[TI], bv[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) av[i] = Ac[(2 * s + hh) * RSA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bv[j] = Bc[(2 * s + hh) * RSB + 32 * j];
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) sstore((kt + 1) & 1, kt + 1);
         __syncthreads();
     }
 
-    int nc[2];
-    bool nok[2];
+    int nc[TJ];
+    bool nok[TJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + r;
+    for (int j = 0; j < TJ; ++j) {
+        const int n = n0 + wn * 32 * TJ + j * 32 + r;
         nok[j] = n < a.N;
         nc[j] = nok[j] ? n : a.N - 1;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        float old[16][2];
+    for (int i = 0; i < TI; ++i) {
+        float old[16][TJ];
         size_t ro[16];
         bool rok[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int m = m0 + wm * 64 + i * 32 + 8 * (e >> 2) + 4 * hh + (e & 3);
+            const int m = m0 + wm * 32 * TI + i * 32 + 8 * (e >> 2) + 4 * hh + (e & 3);
             rok[e] = m < a.M;
             ro[e] = (size_t)(rok[e] ? m : a.M - 1) * a.c_ms;
         }
@@ -123,12 +138,12 @@ __global__ __launch_bounds__(256, 2) void bgemm_kernel(BgemmArgs a)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) old[e][j] = C[ro[e] + nc[j]];
+                for (int j = 0; j < TJ; ++j) old[e][j] = C[ro[e] + nc[j]];
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < TJ; ++j) {
                 float v = acc[i][j][e] * a.alpha;
                 if (a.accumulate) v += old[e][j];
                 if (rok[e] && nok[j]) C[ro[e] + nc[j]] = v;
@@ -144,13 +159,23 @@ extern "C" int mg_bgemm(const float *A, const float *B, float *C, int M, int N, 
     if (M <= 0 || N <= 0 || K <= 0 || batch <= 0 || heads <= 0) return MG_ERR_SHAPE;
     if ((a_ms != 1 && a_ks != 1) || (b_ks != 1 && b_ns != 1) || c_ms < N) return MG_ERR_SHAPE;
     BgemmArgs a{A, B, C, M, N, K, heads, a_ms, a_ks, a_bs, a_hs, b_ks, b_ns, b_bs, b_hs, c_ms, c_bs, c_hs, alpha, accumulate};
-    dim3 grid(mg_cdiv(N, BG_BM), mg_cdiv(M, BG_BM), batch * heads);
     const bool amc = a_ms == 1, bnc = b_ns == 1;
     hipStream_t st = (hipStream_t)stream;
-    if (amc && bnc) hipLaunchKernelGGL((bgemm_kernel<true, true>), grid, dim3(256), 0, st, a);
-    else if (amc) hipLaunchKernelGGL((bgemm_kernel<true, false>), grid, dim3(256), 0, st, a);
-    else if (bnc) hipLaunchKernelGGL((bgemm_kernel<false, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((bgemm_kernel<false, false>), grid, dim3(256), 0, st, a);
+    const bool small = (long)mg_cdiv(N, 128) * mg_cdiv(M, 128) * batch * heads < 512;
+#define BG_LAUNCH(AM, BN)                                                                                     \
+    do {                                                                                                      \
+        if (small)                                                                                            \
+            hipLaunchKernelGGL((bgemm_kernel<AM, BN, 1, 1>), dim3(mg_cdiv(N, 64), mg_cdiv(M, 64), batch * heads), \
+                               dim3(256), 0, st, a);                                                          \
+        else                                                                                                  \
+            hipLaunchKernelGGL((bgemm_kernel<AM, BN, 2, 2>), dim3(mg_cdiv(N, 128), mg_cdiv(M, 128), batch * heads), \
+                               dim3(256), 0, st, a);                                                          \
+    } while (0)
+    if (amc && bnc) BG_LAUNCH(true, true);
+    else if (amc) BG_LAUNCH(true, false);
+    else if (bnc) BG_LAUNCH(false, true);
+    else BG_LAUNCH(false, false);
+#undef BG_LAUNCH
     MG_LAUNCH_CHECK();
     return MG_OK;
 }

@@ -5,6 +5,8 @@
 // of each output), dropout keep-masks are uint8 [B, C, L] made by the caller (so tests can inject them).
 #include "common.h"
 
+#define MG_LN_SLOTS 32
+
 // ---------------------------------------------------------------------------------------------
 // pre = a * keep * drop_scale + res;  out = pad ? 0 : LN_c(pre) * gamma + beta          (C == 256)
 // 256 threads = 32 frames x 8 channel groups, as the inference kernel (attention.hip).
@@ -153,9 +155,10 @@ __global__ __launch_bounds__(256) void layernorm_train_bwd_kernel(const float *_
             pg += __shfl_xor(pg, o2, 64);
             pb += __shfl_xor(pb, o2, 64);
         }
-        if (f == 0) {
-            atomicAdd(dgamma + c, pg);
-            atomicAdd(dbeta + c, pb);
+        if (f == 0) {   // MG_LN_SLOTS copies of the two vectors: 1/32 of the same-address contention
+            const int slot = (blockIdx.x + blockIdx.y) % MG_LN_SLOTS;
+            atomicAdd(dgamma + slot * C + c, pg);
+            atomicAdd(dbeta + slot * C + c, pb);
         }
     }
 }
@@ -172,7 +175,8 @@ extern "C" int mg_layernorm_cm_train_fwd(const float *a, const uint8_t *keep, fl
     return MG_OK;
 }
 
-// dgamma / dbeta [C] are ACCUMULATED into (the caller zeroes or carries them).
+// dgamma / dbeta are [MG_LN_SLOTS = 32][C] partial sums, ACCUMULATED into (the caller zeroes them and adds the 32
+// rows: one same-address atomic per channel per workgroup costs 5x the kernel's HBM time otherwise).
 extern "C" int mg_layernorm_cm_bwd(const float *pre, const float *dy, const float *gamma, const uint8_t *pad,
                                    const uint8_t *keep, float drop_scale, float *d_pre, float *d_a, float *dgamma,
                                    float *dbeta, int B, int C, int L, float eps, void *stream)

@@ -346,11 +346,11 @@ def layernorm_cm_bwd(pre, dy, gamma, pad, keep, drop_scale, eps=1e-5):
     B, C, L = pre.shape
     d_pre = torch.empty_like(pre)
     d_a = torch.empty_like(pre) if keep is not None else None
-    dg = torch.zeros(C, device=pre.device, dtype=torch.float32)
-    db = torch.zeros(C, device=pre.device, dtype=torch.float32)
+    part = torch.zeros(2, 32, C, device=pre.device, dtype=torch.float32)     # 32 partial-sum slots per vector
     check(Lb.mg_layernorm_cm_bwd(fptr(pre), fptr(dy), fptr(gamma), _u8(pad), _u8(keep), float(drop_scale), fptr(d_pre),
-                                 fptr(d_a, True), fptr(dg), fptr(db), B, C, L, float(eps), stream_ptr()))
-    return d_pre, (d_a if d_a is not None else d_pre), dg, db
+                                 fptr(d_a, True), fptr(part[0]), fptr(part[1]), B, C, L, float(eps), stream_ptr()))
+    dgb = part.sum(1)
+    return d_pre, (d_a if d_a is not None else d_pre), dgb[0], dgb[1]
 
 
 def bn_stats(x):

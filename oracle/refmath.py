@@ -214,7 +214,7 @@ def diffuse_trace(buf, x_start, mask, T, tape):
     keep = ~mask.unsqueeze(-1)
     out = [norm_spec(x_start, buf["spec_min"], buf["spec_max"]).clamp(-1.0, 1.0) * keep]
     for i in range(T):
-        t = torch.full((B,), i, dtype=torch.long)
+        t = torch.full((B,), i, dtype=torch.long, device=x_start.device)
         out.append(diffuse_fn(buf, x_start, t, tape((B, 1, M, L)))[:, 0].transpose(1, 2) * keep)
     return out
 

@@ -273,8 +273,64 @@ def data_bench():
     print(json.dumps(out), flush=True)
 
 
+def aux_bench():
+    """the aux-mode acoustic step (Decoder 6 FFT blocks -> mel_linear -> PostNet ->
+    diffuse_trace -> losses -> backward -> ScheduledOptim) at B=8, L=1000 on the HIP path, next to the same
+    chain as stock PyTorch-ROCm eager (oracle on the GPU, torch autograd)."""
+    from oracle import refmath as R, schedule as S
+    dev = torch.device("cuda", 0)
+    d = tempfile.mkdtemp()
+    stats = write_stats(d, [-11.5] * 80, [2.0] * 80)
+    args, pre, mc, tr = hot_path_configs("aux", 4, stats_dir=stats, max_seq_len=1000)
+    tr = dict(tr)
+    tr["optimizer_fs2"] = {"betas": [0.9, 0.98], "eps": 1e-9, "weight_decay": 0.0, "warm_up_step": 4000,
+                           "anneal_steps": [300000], "anneal_rate": 0.3}
+    tr.setdefault("optimizer", {})["grad_clip_thresh"] = 1.0
+    B, L = 8, 1000
+    net = mg.MixGANTTS(args, pre, mc, tr).to(dev).train()
+    params = [p for n_, p in net.named_parameters() if n_.split(".")[0] in ("decoder", "mel_linear", "postnet")
+              and p.requires_grad]
+    trainer = mg.AuxTrainer(net, tr, mc, params=params)
+    cond = torch.randn(B, L, 256, device=dev)
+    mel = torch.rand(B, L, 80, device=dev) * 13.5 - 11.5
+    pad = torch.zeros(B, L, dtype=torch.bool, device=dev)
+    t_ours = timeit(lambda: trainer.step(cond.clone().requires_grad_(), mel, pad), 2, 5)
+    if os.environ.get("MG_AUX_OURS_ONLY"):
+        print(json.dumps({"ours_ms": round(t_ours * 1e3, 2)}), flush=True)
+        return
+    # stock eager: same parameters, torch autograd + torch dropout masks + torch Adam
+    W = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k and "position_enc" not in k)
+         for k, v in net.state_dict().items() if k.split(".")[0] in ("decoder", "mel_linear", "postnet")}
+    buf = {k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in
+           S.diffusion_buffers(S.beta_schedule("vpsde", 4, 0.1, 40, 0.008)).items()}
+    buf["spec_min"], buf["spec_max"] = net.diffusion.spec_min, net.diffusion.spec_max
+    opt = torch.optim.Adam([w for w in W.values() if w.requires_grad], betas=(0.9, 0.98), eps=1e-9)
+    drop = lambda shape, p: (torch.rand(shape, device=dev) >= p).float()  # noqa: E731
+
+    class _Noise:
+        def next(self, shape=None):
+            return torch.randn(B, 1, 80, L, device=dev)
+        __call__ = next
+
+    def stock():
+        c = cond.clone().requires_grad_()
+        tape = R.NoiseTape([torch.randn(B, 1, 80, L, device=dev) for _ in range(4)])
+        ml, pl, _ = R.aux_acoustic_losses(W, buf, c, mel, pad, 1000, 4, tape, drop)
+        (ml + pl).backward()
+        torch.nn.utils.clip_grad_norm_([w for w in W.values() if w.requires_grad], 1.0)
+        opt.step()
+        opt.zero_grad()
+
+    t_stock = timeit(stock, 2, 5)
+    print(json.dumps({"config": "f4 aux acoustic train step, B=8, L=1000 (decoder 6 FFT blocks + PostNet, fwd+bwd+opt)",
+                      "ours_ms": round(t_ours * 1e3, 2), "stock_pytorch_rocm_eager_ms": round(t_stock * 1e3, 2),
+                      "speedup": round(t_stock / t_ours, 2)}), flush=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "data":
+    if len(sys.argv) > 1 and sys.argv[1] == "aux":
+        aux_bench()
+    elif len(sys.argv) > 1 and sys.argv[1] == "data":
         data_bench()
     elif len(sys.argv) > 1 and sys.argv[1] == "stock":
         stock_eager_bench()
