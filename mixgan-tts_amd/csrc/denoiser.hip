@@ -388,17 +388,35 @@ extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, c
             a.sig_save = save ? ws + w.sig + (size_t)l * w.act_stride : nullptr;
             a.tnh_save = save ? ws + w.tnh + (size_t)l * w.act_stride : nullptr;
             a.L = L;
-            a.tiles_per_b = mg_cdiv(L, RB_NT);
             a.first = (l == 0);
+            // Tile width: 64 frames unless that leaves more than ~1/4 of the 256 CUs without a workgroup AND a
+            // narrow tiling still fits one workgroup per CU (a second round would cost more than it gains).
+            const long w64 = (long)mg_cdiv(L, RB_NT) * B, w30 = (long)mg_cdiv(L, 30) * B, w32 = (long)mg_cdiv(L, 32) * B;
+            int ntile = w64 > 192 ? 64 : (w30 <= 256 ? 30 : (w32 <= 256 ? 32 : 64));
+            if (const char *force = std::getenv("MG_RB_TILE")) {   // tests pin each tile width against the fixtures
+                const int f = std::atoi(force);
+                if (f == 64 || f == 30 || f == 32) ntile = f;
+            }
+            a.tiles_per_b = mg_cdiv(L, ntile);
             dim3 grid((unsigned)(a.tiles_per_b * B));
             prof_mark(st, 0);
-            if (save) {
-                if (vec4) hipLaunchKernelGGL((resblock_fused_kernel<true, true>), grid, dim3(512), 0, st, a);
-                else hipLaunchKernelGGL((resblock_fused_kernel<false, true>), grid, dim3(512), 0, st, a);
+#define MG_RB_LAUNCH(V, S, N) hipLaunchKernelGGL((resblock_fused_kernel<V, S, N>), grid, dim3(512), 0, st, a)
+            if (ntile == 64) {
+                if (save) {
+                    if (vec4) MG_RB_LAUNCH(true, true, 64);
+                    else MG_RB_LAUNCH(false, true, 64);
+                } else {
+                    if (vec4) MG_RB_LAUNCH(true, false, 64);
+                    else MG_RB_LAUNCH(false, false, 64);
+                }
+            } else if (ntile == 30) {
+                if (save) MG_RB_LAUNCH(false, true, 30);
+                else MG_RB_LAUNCH(false, false, 30);
             } else {
-                if (vec4) hipLaunchKernelGGL((resblock_fused_kernel<true, false>), grid, dim3(512), 0, st, a);
-                else hipLaunchKernelGGL((resblock_fused_kernel<false, false>), grid, dim3(512), 0, st, a);
+                if (save) MG_RB_LAUNCH(false, true, 32);
+                else MG_RB_LAUNCH(false, false, 32);
             }
+#undef MG_RB_LAUNCH
             prof_mark(st, 1);
             MG_LAUNCH_CHECK();
             float *tmp = (l == 0) ? xc : xa;  // after layer 0 the pair is (ws.y, ws.x)

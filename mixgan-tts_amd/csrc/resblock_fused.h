@@ -35,6 +35,29 @@
 #define RB_H_FLOATS (RB_C * RB_RSH)
 #define RB_LDS_FLOATS (RB_COND_FLOATS + RB_H_FLOATS)
 
+// Narrow-tile variants for launches whose 64-frame tiling would leave most CUs idle (one utterance, small
+// batches, the 8-per-GPU training shard): a workgroup owns 30 or 32 output frames, every GEMM-2/3 has a single
+// 32-column n-block and the LDS footprint is 78 KB.
+//   NTU = 30: the halo frame on each side + 30 outputs = exactly one 32-column block in GEMM 1 too (6.7 % of
+//             the columns are halo); hT columns 32, 33 (read by the two scratch output columns) are zeroed.
+//   NTU = 32: 34 h columns -> GEMM 1 runs a second n-block for 2 columns (+20 % MFMAs), but 32 divides the
+//             frame axis 6 % finer: B=8, L=1000 is exactly 256 workgroups = one per CU instead of 272.
+//   condT [256][40] (+32)  col 3 + j <-> frame l0-1+j      hT [256][36]  col j <-> frame l0-1+j
+//   gT    [256][32]        col j <-> frame l0+j
+template <int NTU_>
+struct RbTile {
+    static_assert(NTU_ == 64 || NTU_ == 30 || NTU_ == 32, "tile widths: 64 (default), 30, 32");
+    static constexpr int NTU = NTU_;
+    static constexpr int NB = NTU_ == 64 ? 2 : 1;                        // n-blocks of GEMM 2 / 3
+    static constexpr int NB1 = NTU_ == 64 ? 3 : (NTU_ == 32 ? 2 : 1);    // n-blocks of GEMM 1
+    static constexpr int COLS1 = NTU_ + 2;                               // h columns produced
+    static constexpr int RSC = NTU_ == 64 ? RB_RSC : 40;
+    static constexpr int RSH = NTU_ == 64 ? RB_RSH : 36;
+    static constexpr int RSG = NTU_ == 64 ? RB_RSG : 32;
+    static constexpr int COND_FLOATS = RB_C * RSC + 32;
+    static constexpr int LDS_FLOATS = COND_FLOATS + RB_C * RSH;
+};
+
 struct ResArgs {
     const float *cond;  // [B, 256, L]
     const float *x_in;  // [B, 256, L]
@@ -129,12 +152,16 @@ __device__ __forceinline__ void rb_mfma_loop(f32x16 (&acc)[NMB][NNB], const f32x
     }
 }
 
-template <bool VEC4, bool SAVE>
+template <bool VEC4, bool SAVE, int NTILE = 64>
 __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(ResArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float lds[RB_LDS_FLOATS];
+    using TL = RbTile<NTILE>;
+    static_assert(NTILE == 64 || !VEC4, "narrow tiles use the scalar staging path");
+    constexpr int NB = TL::NB, NB1 = TL::NB1, COLS1 = TL::COLS1, NTU = TL::NTU, RSC = TL::RSC, RSH = TL::RSH,
+                  RSG = TL::RSG;
+    __shared__ __attribute__((aligned(16))) float lds[TL::LDS_FLOATS];
     float *condT = lds;
-    float *hT = lds + RB_COND_FLOATS;
+    float *hT = lds + TL::COND_FLOATS;
     float *gT = lds;
 
     const int tid = threadIdx.x;
@@ -142,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(ResArgs a)
     const int w = tid >> 6;
     const int hh = lane >> 5, c32 = lane & 31;
     const int b = blockIdx.x / a.tiles_per_b;
-    const int l0 = (blockIdx.x - b * a.tiles_per_b) * RB_NT;
+    const int l0 = (blockIdx.x - b * a.tiles_per_b) * NTU;
     const int L = a.L;
     const size_t bbase = (size_t)b * RB_C * L;
 
@@ -161,22 +188,22 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(ResArgs a)
                 const int fc = min(max(f0, 0), L - 4);
                 f32x4 v = *reinterpret_cast<const f32x4 *>(cb + (size_t)row * L + fc);
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4 *>(condT + row * RB_RSC + 4 * c4) = ok ? v : z;
+                *reinterpret_cast<f32x4 *>(condT + row * RSC + 4 * c4) = ok ? v : z;
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 33; ++k) {  // 256 rows x 66 frames = 33 x 512
+            for (int k = 0; k < COLS1 / 2; ++k) {  // 256 rows x COLS1 frames = (COLS1 / 2) x 512
                 const int idx = tid + k * 512;
-                const int row = idx / 66, cc = idx - row * 66;
+                const int row = idx / COLS1, cc = idx - row * COLS1;
                 const int f = l0 - 1 + cc;
                 const float v = cb[(size_t)row * L + min(max(f, 0), L - 1)];
-                condT[row * RB_RSC + 3 + cc] = (f >= 0 && f < L) ? v : 0.f;
+                condT[row * RSC + 3 + cc] = (f >= 0 && f < L) ? v : 0.f;
             }
         }
     }
 
     // ---------------------------------------------------------------- GEMM 1: h (66 columns)
-    f32x16 acc1[1][3];
+    f32x16 acc1[1][NB1];
     {
         const float *xb = a.x_in + bbase;
 #pragma unroll
@@ -184,58 +211,61 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(ResArgs a)
             const int row = w * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
             const float add = a.bc[row] + a.hvec[(size_t)b * RB_C + row];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
+            for (int j = 0; j < NB1; ++j) {
                 const int f = l0 - 1 + 32 * j + c32;
-                const bool ok = f >= 0 && f < L && (j < 2 || c32 < 2);
+                const bool ok = f >= 0 && f < L && 32 * j + c32 < COLS1;
                 const float v = xb[(size_t)row * L + min(max(f, 0), L - 1)];
                 acc1[0][j][r] = ok ? v + add : 0.f;
             }
         }
     }
     __syncthreads();
-    rb_mfma_loop<1, 3, 1, RB_RSC>(acc1, reinterpret_cast<const f32x4 *>(a.wc) + (size_t)w * 32 * 64 + lane, 0,
-                                  condT + hh * RB_RSC, 3 + c32);
+    rb_mfma_loop<1, NB1, 1, RSC>(acc1, reinterpret_cast<const f32x4 *>(a.wc) + (size_t)w * 32 * 64 + lane, 0,
+                                 condT + hh * RSC, 3 + c32);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = w * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < NB1; ++j) {
             const int col = 32 * j + c32;
-            if (j < 2 || c32 < 2) {
+            if (col < COLS1) {
                 const int f = l0 - 1 + col;
                 const bool ok = f >= 0 && f < L;  // zero padding of the k=3 conv applies to h
                 const float v = ok ? acc1[0][j][r] : 0.f;
-                hT[row * RB_RSH + col] = v;
-                if (SAVE && ok && col >= 1 && col <= RB_NT) a.h_save[bbase + (size_t)row * L + f] = v;
+                hT[row * RSH + col] = v;
+                if (SAVE && ok && col >= 1 && col <= NTU) a.h_save[bbase + (size_t)row * L + f] = v;
             }
         }
+    }
+    if (NTU == 30) {   // columns 32, 33 of hT are read (taps 1, 2 of the two scratch output columns): keep them finite
+        if (tid < RB_C) hT[tid * RSH + 32] = hT[tid * RSH + 33] = 0.f;
     }
 
     __syncthreads();  // hT complete; condT free
 
     // ---------------------------------------------------------------- GEMM 2: z = W3 (*) h, gate
-    f32x16 acc2[2][2];
+    f32x16 acc2[2][NB];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
-    rb_mfma_loop<2, 2, 3, RB_RSH>(acc2, reinterpret_cast<const f32x4 *>(a.w3) + (size_t)(2 * w) * 96 * 64 + lane, 96 * 64,
-                                  hT + hh * RB_RSH, c32);
+    rb_mfma_loop<2, NB, 3, RSH>(acc2, reinterpret_cast<const f32x4 *>(a.w3) + (size_t)(2 * w) * 96 * 64 + lane, 96 * 64,
+                                hT + hh * RSH, c32);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int ch = w * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
         const float bg = a.b3[ch], bf = a.b3[RB_C + ch];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NB; ++j) {
             const float s = mg_sigmoid(acc2[0][j][r] + bg);
             const float t = mg_tanh(acc2[1][j][r] + bf);
             const int col = 32 * j + c32;
-            gT[ch * RB_RSG + col] = s * t;
+            gT[ch * RSG + col] = s * t;
             if (SAVE) {
                 const int f = l0 + col;
-                if (f < L) {
+                if (f < L && col < NTU) {
                     const size_t o = bbase + (size_t)ch * L + f;
                     a.sig_save[o] = s;
                     a.tnh_save[o] = t;
@@ -246,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(ResArgs a)
     }
     // ---------------------------------------------------------------- GEMM 3's addends: loaded here (acc2 is dead), consumed after GEMM 3
     // wave w owns rows 64w..64w+63 of o: w < 4 -> x rows, w >= 4 -> skip rows
-    f32x16 add3[2][2];
+    f32x16 add3[2][NB];
     {
         const bool xrows = w < 4;
         const float *src = xrows ? a.x_in + bbase : a.skip + bbase;
@@ -261,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(ResArgs a)
                 const int ch = row & (RB_C - 1);
                 const float add = a.bo[row] + use_vec * vec[ch];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NB; ++j) {
                     const int f = min(l0 + 32 * j + c32, L - 1);  // frames >= L are never stored
                     add3[i][j][r] = add + use_src * src[(size_t)ch * L + f];
                 }
@@ -271,15 +301,15 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(ResArgs a)
     __syncthreads();  // gT complete
 
     // ---------------------------------------------------------------- GEMM 3: o = Wo g, residual / skip
-    f32x16 acc3[2][2];
+    f32x16 acc3[2][NB];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc3[i][j][r] = 0.f;
-    rb_mfma_loop<2, 2, 1, RB_RSG>(acc3, reinterpret_cast<const f32x4 *>(a.wo) + (size_t)(2 * w) * 32 * 64 + lane, 32 * 64,
-                                  gT + hh * RB_RSG, c32);
+    rb_mfma_loop<2, NB, 1, RSG>(acc3, reinterpret_cast<const f32x4 *>(a.wo) + (size_t)(2 * w) * 32 * 64 + lane, 32 * 64,
+                                gT + hh * RSG, c32);
     {
         const bool xrows = w < 4;
         float *dst = xrows ? a.x_out + bbase : a.skip + bbase;
@@ -290,9 +320,9 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(ResArgs a)
             for (int r = 0; r < 16; ++r) {
                 const int ch = (w * 64 + i * 32 + 8 * (r >> 2) + 4 * hh + (r & 3)) & (RB_C - 1);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < NB; ++j) {
                     const int f = l0 + 32 * j + c32;
-                    if (f < L) dst[(size_t)ch * L + f] = (acc3[i][j][r] + add3[i][j][r]) * sc;
+                    if (f < L && 32 * j + c32 < NTU) dst[(size_t)ch * L + f] = (acc3[i][j][r] + add3[i][j][r]) * sc;
                 }
             }
         }

@@ -142,6 +142,72 @@ def test_denoiser_forward_golden(mg, manifest, tmp_path, ms):
     assert_close(out.cpu(), g["out"], TOL_SPEC, "Denoiser.forward (north_star budget)")
 
 
+@pytest.mark.parametrize("tile", [64, 30, 32])
+def test_fused_layer_tile_widths(mg, manifest, tmp_path, monkeypatch, tile):
+    """The residual-layer kernel has three tile widths (64 frames; 30 / 32 for launches that would under-fill the
+    chip).  Each one, forced through MG_RB_TILE, against the reference fixture (forward) and against the oracle
+    at ragged sizes, with and without the activation saves of the training forward."""
+    monkeypatch.setenv("MG_RB_TILE", str(tile))
+    g = golden("denoiser_ms1")
+    _, pre, mc, _ = hot_path_configs(multi_speaker=True, stats_dir=str(tmp_path))
+    den = mg.Denoiser(pre, mc)
+    load_seeded(den, manifest, "denoiser_ms1", 22)
+    den = den.cuda()
+    with torch.no_grad():
+        out = den(dev(g["x"]), dev(g["t"]), dev(g["cond"]), dev(g["spk"]))
+    assert_close(out.cpu(), g["out"], TOL, "Denoiser.forward tile %d" % tile)
+    W, _ = seeded(manifest, "denoiser_ms1", 22, requires_grad=True)
+    gen = torch.Generator().manual_seed(tile)
+    for B, L in [(1, 1), (2, 31), (3, 129), (1, 300)]:
+        x = torch.randn(B, 1, 80, L, generator=gen)
+        cond = torch.randn(B, 256, L, generator=gen)
+        spk = torch.randn(B, 256, generator=gen)
+        t = torch.randint(0, 1000, (B,), generator=gen)
+        go = torch.randn(B, 1, 80, L, generator=gen)
+        co = cond.clone().requires_grad_()
+        ref = R.denoiser_forward(W, "", x, t, co, spk)
+        (ref * go).sum().backward()
+        with torch.no_grad():
+            out = den(x.cuda(), t.cuda(), cond.cuda(), spk.cuda())
+        assert_close(out.cpu(), ref.detach(), TOL, "tile %d forward B=%d L=%d" % (tile, B, L))
+        cg = cond.cuda().requires_grad_()
+        out = den(x.cuda(), t.cuda(), cg, spk.cuda())            # grad-enabled: the SAVE instantiation
+        assert_close(out.detach().cpu(), ref.detach(), TOL, "tile %d saving forward" % tile)
+        (out * go.cuda()).sum().backward()
+        assert_close(cg.grad.cpu(), co.grad, TOL, "tile %d d_cond" % tile)
+        for p in den.parameters():
+            p.grad = None
+        for w in W.values():
+            w.grad = None
+
+
+def test_fused_layer_narrow_tiles_equal_wide_bitwise(mg, manifest, tmp_path, monkeypatch):
+    """Every output element sees the same k order whatever the tile width, so B=8 x L=1000 (the per-GPU training
+    shard: 256 workgroups of 32 frames) must reproduce the 64-frame tiling bit for bit."""
+    _, pre, mc, _ = hot_path_configs(stats_dir=str(tmp_path))
+    den = mg.Denoiser(pre, mc)
+    load_seeded(den, manifest, "denoiser_ms0", 77)
+    den = den.cuda()
+    gen = torch.Generator().manual_seed(8)
+    B, L = 8, 1000
+    x = torch.randn(B, 1, 80, L, generator=gen).cuda()
+    cond = torch.randn(B, 256, L, generator=gen).cuda()
+    t = torch.randint(0, 1000, (B,), generator=gen).cuda()
+    outs = {}
+    for tile in (None, 64, 30):
+        if tile is None:
+            monkeypatch.delenv("MG_RB_TILE", raising=False)      # heuristic: 32-frame tiles here
+        else:
+            monkeypatch.setenv("MG_RB_TILE", str(tile))
+        with torch.no_grad():
+            outs[tile] = den(x, t, cond, None).clone()
+    assert torch.equal(outs[None], outs[64]) and torch.equal(outs[30], outs[64])
+    W, _ = seeded(manifest, "denoiser_ms0", 77)
+    with torch.no_grad():
+        ref = R.denoiser_forward(W, "", x[:2].cpu(), t[:2].cpu(), cond[:2].cpu(), None)
+    assert_close(outs[None][:2].cpu(), ref, TOL, "B=8 L=1000 vs oracle")
+
+
 def test_denoiser_vs_oracle_ragged_batch(mg, manifest, tmp_path):
     """Sizes the fixtures do not cover: B not a power of two, L crossing tile boundaries."""
     _, pre, mc, _ = hot_path_configs(stats_dir=str(tmp_path))
