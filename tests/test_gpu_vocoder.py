@@ -117,3 +117,27 @@ def test_generator_cpu_input_fails_loudly(mg):
     G = mg.vocoder.Generator(_h())
     with pytest.raises(mg._lib.MixganHipError):
         G(torch.zeros(1, 80, 4))
+
+
+def test_generator_full_size_properties(mg, manifest):
+    """BASELINE-size utterances (L = 1000 frames -> 256,000 samples): rows of a batch are independent (bitwise:
+    a row alone equals the row inside a batch of 3), the output length is exactly 256 L, values stay in [-1, 1],
+    and the first 25 frames' worth of samples only depend on the first frames (finite receptive field), checked
+    against the oracle on a truncated input."""
+    g = golden("hifigan")
+    G = _seeded_generator(mg, manifest, g)
+    gen = torch.Generator().manual_seed(4)
+    mel = (torch.rand(3, 80, 1000, generator=gen) * 13.5 - 11.5)
+    y = G(mel.cuda())
+    assert tuple(y.shape) == (3, 1, 256000)
+    assert torch.isfinite(y).all() and y.abs().max().item() <= 1.0
+    for b in range(3):
+        assert torch.equal(G(mel[b:b + 1].cuda())[0], y[b]), "row %d depends on its batch" % b
+    # receptive field of HiFi-GAN V1 at the mel rate is < 40 frames on each side: compare the first 25 frames'
+    # samples with the oracle run on the first 80 frames only
+    W, _ = seeded(manifest, "hifigan", 81)
+    for k in g:
+        if k.startswith("gain/"):
+            W[k[5:]] = T(g[k])
+    ref = R.hifigan_forward(W, mel[:1, :, :80])
+    assert_close(y[:1, :, :25 * 256].cpu(), ref[:, :, :25 * 256], TOL, "full-size head vs oracle on a truncated input")
