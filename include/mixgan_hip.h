@@ -306,6 +306,10 @@ int mg_mel_l1_bwd(const float *pred, const float *targ, const uint8_t *pad, int 
  * out [B, n_head*d_head, L]; scale = 1/temperature = 1/sqrt(d_k).  d_head must be 128. */
 int mg_attention_fwd(const float *qkv, const uint8_t *key_pad, float *out, int B, int L, int n_head,
                      int d_head, float scale, void *stream);
+/* The same function with fp16 MFMA operands (q*scale, k, v and the probabilities rounded to fp16; fp32
+ * accumulation, softmax statistics and I/O): BASELINE configs[4]'s "fp16 MFMA attention path" for L = 4000. */
+int mg_attention_fwd_f16(const float *qkv, const uint8_t *key_pad, float *out, int B, int L, int n_head,
+                     int d_head, float scale, void *stream);
 /* Post-LayerNorm on the channel-major layout (SubLayers.py:55,91 + Layers.py:25,28):
  * out[b,c,l] = pad[b,l] ? 0 : LN_c(a[b,:,l] + res[b,:,l]) * gamma[c] + beta[c];  C must be 256. */
 int mg_layernorm_cm_fwd(const float *a, const float *res, const float *gamma, const float *beta,

@@ -19,7 +19,7 @@ EXPORTS = (
     "mg_denoiser_bwd_workspace_floats", "mg_denoiser_bwd",
     "mg_profile_begin", "mg_profile_begin_sampled", "mg_profile_end", "mg_transpose_bml_strided", "mg_act_bwd", "mg_upsample_zero",
     "mg_step_mlp_fwd", "mg_step_mlp_bwd", "mg_linear_small_fwd", "mg_linear_small_bwd",
-    "mg_loss_sum", "mg_loss_grad", "mg_mel_l1_fwd", "mg_mel_l1_bwd", "mg_attention_fwd", "mg_layernorm_cm_fwd",
+    "mg_loss_sum", "mg_loss_grad", "mg_mel_l1_fwd", "mg_mel_l1_bwd", "mg_attention_fwd", "mg_attention_fwd_f16", "mg_layernorm_cm_fwd",
     "mg_length_regulate_fwd", "mg_length_regulate_bwd", "mg_word_pool_fwd", "mg_word_pool_bwd", "mg_mapping_mask",
     "mg_rel_coef",
 )
@@ -114,6 +114,7 @@ def _declare(L):
         "mg_mel_l1_fwd": (i, [vp, vp, vp, i, i, vp, vp]),
         "mg_mel_l1_bwd": (i, [vp, vp, vp, i, i, vp, vp, vp, vp]),
         "mg_attention_fwd": (i, [vp, vp, vp, i, i, i, i, f, vp]),
+        "mg_attention_fwd_f16": (i, [vp, vp, vp, i, i, i, i, f, vp]),
         "mg_layernorm_cm_fwd": (i, [vp, vp, vp, vp, vp, vp, i, i, i, f, vp]),
         "mg_length_regulate_fwd": (i, [vp, vp, vp, vp, i, i, i, i, vp]),
         "mg_length_regulate_bwd": (i, [vp, vp, vp, i, i, i, i, vp]),

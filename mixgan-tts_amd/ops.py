@@ -263,12 +263,15 @@ def linear_small_bwd(g, x, W, want_dx=True):
     return dx, dW
 
 
-def attention(qkv, key_pad, n_head, d_head):
-    """qkv [B, 3*n_head*d_head, L] -> [B, n_head*d_head, L] (mg_attention_fwd)."""
+def attention(qkv, key_pad, n_head, d_head, precision="fp32"):
+    """qkv [B, 3*n_head*d_head, L] -> [B, n_head*d_head, L] (mg_attention_fwd; precision "f16": fp16 MFMA operands)."""
     L = _lib.lib()
     B, _, Lf = qkv.shape
     out = torch.empty(B, n_head * d_head, Lf, device=qkv.device, dtype=torch.float32)
-    check(L.mg_attention_fwd(fptr(qkv), iptr(key_pad, torch.uint8, True), fptr(out), B, Lf, n_head, d_head,
+    if precision not in ("fp32", "f16"):
+        raise ValueError("attention precision must be 'fp32' or 'f16', got %r" % (precision,))
+    fn = L.mg_attention_fwd if precision == "fp32" else L.mg_attention_fwd_f16
+    check(fn(fptr(qkv), iptr(key_pad, torch.uint8, True), fptr(out), B, Lf, n_head, d_head,
                              float(d_head) ** -0.5, stream_ptr()))
     return out
 

@@ -74,6 +74,9 @@ class MultiHeadAttention(nn.Module):
         self.layer_norm = nn.LayerNorm(d_model)      # parameter holder; evaluated by mg_layernorm_cm_fwd
         self.fc = _Linear(n_head * d_v, d_model)
         self.dropout_p = dropout
+        # eval-mode contraction precision: "fp32" (exact, default) or "f16" (fp16 MFMA operands, fp32 accumulate:
+        # BASELINE configs[4]'s long-form path; set through Decoder.set_attention_precision)
+        self.precision = "fp32"
 
     def forward_cm(self, x, pad8, fill=False):
         """x [B, D, L] channel-major, pad8 uint8 [B, L] -> LayerNorm(fc(attn) + x), [B, D, L].
@@ -84,7 +87,7 @@ class MultiHeadAttention(nn.Module):
         bq = torch.cat([self.w_qs.bias, self.w_ks.bias, self.w_vs.bias]).detach()
         D = self.w_qs.weight.shape[1]
         qkv = ops.conv1d_packed(x, wq, bq, 3 * self.n_head * self.d_k, 1)
-        att = ops.attention(qkv, pad8, self.n_head, self.d_k)
+        att = ops.attention(qkv, pad8, self.n_head, self.d_k, self.precision)
         y = ops.conv1d_packed(att, ops.pack_cached(self.fc.weight[:, :, None]), self.fc.bias.detach(), D, 1)
         return ops.layernorm_cm(y, x, self.layer_norm.weight.detach(), self.layer_norm.bias.detach(),
                                 pad8 if fill else None, self.layer_norm.eps)
@@ -168,6 +171,13 @@ class Decoder(nn.Module):
         self.layer_stack = nn.ModuleList([
             FFTBlock(d_model, tc["decoder_head"], d_k, d_v, tc["conv_filter_size"], tc["conv_kernel_size"],
                      dropout=tc["decoder_dropout"]) for _ in range(tc["decoder_layer"])])
+
+    def set_attention_precision(self, precision):
+        """"fp32" | "f16" for the eval-mode attention of every layer (training always runs fp32)."""
+        if precision not in ("fp32", "f16"):
+            raise ValueError("attention precision must be 'fp32' or 'f16', got %r" % (precision,))
+        for layer in self.layer_stack:
+            layer.slf_attn.precision = precision
 
     def forward_cm(self, enc_seq, mask):
         """enc_seq [B, L, D], mask bool [B, L] True = pad -> channel-major [B, D, L'] and the (possibly

@@ -327,8 +327,26 @@ def aux_bench():
                       "speedup": round(t_stock / t_ours, 2)}), flush=True)
 
 
+def attention_bench():
+    """BASELINE configs[4] attention shape: B=16 per GPU, L=4000, 2 heads x 128: exact fp32 MFMA kernel vs the
+    fp16-operand one (both streaming softmax, no L x L tensor)."""
+    dev = torch.device("cuda", 0)
+    for B, L in ((16, 1000), (16, 4000)):
+        qkv = torch.randn(B, 768, L, device=dev)
+        pad = torch.zeros(B, L, dtype=torch.uint8, device=dev)
+        fl = 4.0 * L * L * 128 * 2 * B
+        t32 = timeit(lambda: mg.ops.attention(qkv, pad, 2, 128), 2, 5)
+        t16 = timeit(lambda: mg.ops.attention(qkv, pad, 2, 128, precision="f16"), 2, 5)
+        err = float((mg.ops.attention(qkv, pad, 2, 128) - mg.ops.attention(qkv, pad, 2, 128, precision="f16")).abs().max())
+        print(json.dumps({"config": "attention B=%d L=%d" % (B, L), "fp32_ms": round(t32 * 1e3, 3),
+                          "fp32_TFLOPs": round(fl / t32 / 1e12, 1), "f16_ms": round(t16 * 1e3, 3),
+                          "f16_TFLOPs": round(fl / t16 / 1e12, 1), "max_abs_diff": err}), flush=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "aux":
+    if len(sys.argv) > 1 and sys.argv[1] == "attention":
+        attention_bench()
+    elif len(sys.argv) > 1 and sys.argv[1] == "aux":
         aux_bench()
     elif len(sys.argv) > 1 and sys.argv[1] == "data":
         data_bench()

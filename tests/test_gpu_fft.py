@@ -147,3 +147,31 @@ def test_attention_long_form_L4000(mg, manifest):
     blk = blk.cuda().eval()
     y = blk.slf_attn.forward_cm(mg.ops.transpose_bml(x.cuda(), False), pad.to(torch.uint8).cuda())
     assert_close(mg.ops.transpose_bml(y, True).cpu(), ref, 3e-5, "MHA L=4000")
+
+
+@pytest.mark.parametrize("B,L,lens", [(2, 300, [300, 171]), (3, 64, [64, 1, 33]), (1, 129, [129]), (1, 4000, [3777])])
+def test_attention_f16_mfma_path(mg, manifest, B, L, lens):
+    """BASELINE configs[4]: attention with fp16 MFMA operands (fp32 accumulate / statistics) against the exact
+    fp32 kernel at the north_star tolerance, including the L = 4000 long-form length."""
+    H, d = 2, 128
+    gen = torch.Generator().manual_seed(L + B)
+    qkv = torch.randn(B, 3 * H * d, L, generator=gen).cuda()
+    pad = (torch.arange(L)[None, :] >= torch.tensor(lens)[:, None]).to(torch.uint8).cuda()
+    ref = mg.ops.attention(qkv, pad, H, d)
+    got = mg.ops.attention(qkv, pad, H, d, precision="f16")
+    assert torch.isfinite(got).all()
+    assert_close(got.cpu(), ref.cpu(), 1e-3, "attention f16 vs fp32, L=%d" % L)   # north_star tolerance
+    with pytest.raises(ValueError):
+        mg.ops.attention(qkv, pad, H, d, precision="fp8")
+
+
+def test_decoder_golden_with_f16_attention(mg, manifest):
+    g = golden("decoder")
+    _, pre, mc, _ = hot_path_configs(stats_dir=".", max_seq_len=int(g["max_seq_len"]))
+    dec = mg.Decoder(mc)
+    load_seeded(dec, manifest, "decoder", 52)
+    dec = dec.cuda().eval()
+    dec.set_attention_precision("f16")
+    for tag in ("short", "long"):
+        y = dec(dev(g[tag + "_x"]), dev(g[tag + "_pad"]))
+        assert_close(y.cpu(), g[tag + "_out"], 1e-3, "Decoder (f16 attention) " + tag)
