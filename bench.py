@@ -293,12 +293,28 @@ def cpu_baseline(gd, B, L):
     cond = torch.randn(B, 256, L, generator=g)
     t = torch.full((B,), 3, dtype=torch.long)
     times = []
+    parity = None
     t_start = time.perf_counter()
     for i in range(12):
         nz = torch.randn(B, 1, MEL, L, generator=g)
         t0 = time.perf_counter()
-        R.p_sample(W, buf, x, t, cond, None, nz)
+        ref = R.p_sample(W, buf, x, t, cond, None, nz)
         times.append(time.perf_counter() - t0)
+        if parity is None:
+            # BASELINE metric, second half ("mel L1 vs ref"): the same step on the HIP path, same weights, inputs
+            # and noise, against the CPU restatement just timed (the oracle is the checker here, not the product)
+            dev = next(gd.parameters()).device
+            saved = gd.noise_fn
+            gd.noise_fn = lambda shape: nz
+            try:
+                with torch.no_grad():
+                    ours = gd.p_sample(x.to(dev), t.to(dev), cond.to(dev), None).cpu()
+            finally:
+                gd.noise_fn = saved
+            diff = (ours - ref).abs()
+            parity = {"mel_l1_vs_cpu_ref": float(diff.mean()), "max_abs_err": float(diff.max()),
+                      "max_rel_err": float(diff.max() / ref.abs().max()), "tolerance": 1e-3,
+                      "what": "x_{t-1} of one p_sample step (normalised mel units), B=%d, L=%d" % (B, L)}
         if time.perf_counter() - t_start > 20 and len(times) >= 3:
             break
     med = float(np.median(times[1:])) if len(times) > 1 else times[0]
@@ -313,7 +329,7 @@ def cpu_baseline(gd, B, L):
         pass
     return {"value": round(1.0 / med, 4), "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": "%d timed p_sample steps (median, 1 warm-up dropped) at the same B=%d, L=%d on %s"
-                      % (max(1, len(times) - 1), B, L, model)}
+                      % (max(1, len(times) - 1), B, L, model), "parity": parity}
 
 
 if __name__ == "__main__":
