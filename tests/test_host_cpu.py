@@ -81,3 +81,31 @@ def test_product_does_not_import_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), fn
+
+
+def test_oracle_is_only_used_as_a_checker():
+    """Outside tests/ the oracle may be imported only by __graft_entry__.smoke() and bench.py's cpu_baseline leg
+    (task statement, section 3); tools/ and the package must not touch it, and nothing at the repo root reads
+    /root/reference at run time (it does not exist on the GPU box)."""
+    allowed = {"bench.py": "def cpu_baseline", "__graft_entry__.py": "def smoke"}
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
+    for dirpath, dirs, files in os.walk(ROOT):
+        dirs[:] = [d for d in dirs if d not in (".git", "tests", "oracle", "gpurun_out", "__pycache__", ".pytest_cache")]
+        for fn in files:
+            if not fn.endswith(".py"):
+                continue
+            path = os.path.join(dirpath, fn)
+            txt = open(path).read()
+            rel = os.path.relpath(path, ROOT)
+            for m in pat.finditer(txt):
+                assert rel in allowed, "%s imports the oracle" % rel
+                # the import must sit inside the one function that is allowed to use it
+                head = txt[:m.start()]
+                last_def = head.rfind("\ndef ")
+                assert txt[last_def + 1:].startswith(allowed[rel]), "%s: oracle import outside %s" % (rel, allowed[rel])
+    for fn in ("bench.py", "__graft_entry__.py"):
+        assert "/root/reference" not in open(os.path.join(ROOT, fn)).read(), fn
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "mixgan-tts_amd")):
+        for fn in files:
+            if fn.endswith(".py"):
+                assert "/root/reference" not in open(os.path.join(dirpath, fn)).read(), fn
