@@ -150,3 +150,49 @@ class Generator(nn.Module):
         # F.leaky_relu(x) with the DEFAULT slope 0.01 (hifigan/models.py:161), conv_post, tanh
         return ops.conv1d_packed(x, self.conv_post.packed(ops.PACK_PLAIN), self.conv_post.bias.detach(), 1, 7, 1, 3,
                                  act="tanh", alpha=scale, in_slope=0.01)
+
+
+class AttrDict(dict):
+    """hifigan/__init__.py / env.py: json config with attribute access."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.__dict__ = self
+
+
+def get_vocoder(config, device, config_path="hifigan/config.json", checkpoint_path=None):
+    """utils/model.py:74-105 for `vocoder.model == "HiFi-GAN"`: build from hifigan/config.json, load the
+    `generator` state dict of hifigan/generator_<speaker>.pth.tar, eval, remove_weight_norm, move to the device.
+    (MelGAN comes from torch.hub -- a download -- and is not mirrored.)"""
+    import json
+    name = config["vocoder"]["model"]
+    speaker = config["vocoder"]["speaker"]
+    if name != "HiFi-GAN":
+        raise NotImplementedError("vocoder %r: only HiFi-GAN is on the HIP path" % name)
+    with open(config_path, "r") as f:
+        h = AttrDict(json.load(f))
+    vocoder = Generator(h)
+    if checkpoint_path is None:
+        checkpoint_path = "hifigan/generator_%s.pth.tar" % speaker
+    ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+    vocoder.load_state_dict(ckpt["generator"])
+    vocoder.eval()
+    vocoder.remove_weight_norm()
+    vocoder.to(device)
+    return vocoder
+
+
+def vocoder_infer(mels, vocoder, model_config, preprocess_config, lengths=None):
+    """utils/model.py:108-126: mels [B, 80, L] -> list of int16 numpy waveforms (cropped to `lengths`).  The scaling
+    and the int16 conversion run on the device, so the host copy is half the bytes of the reference's."""
+    if model_config["vocoder"]["model"] != "HiFi-GAN":
+        raise NotImplementedError("only HiFi-GAN is on the HIP path")
+    with torch.no_grad():
+        wavs = vocoder(mels).squeeze(1)
+        scaled = wavs * float(preprocess_config["preprocessing"]["audio"]["max_wav_value"])
+        wavs = scaled.to(torch.int32).to(torch.int16).cpu().numpy()     # truncation toward zero, as numpy's astype
+    wavs = [w for w in wavs]
+    for i in range(len(mels)):
+        if lengths is not None:
+            wavs[i] = wavs[i][: lengths[i]]
+    return wavs

@@ -141,3 +141,27 @@ def test_generator_full_size_properties(mg, manifest):
             W[k[5:]] = T(g[k])
     ref = R.hifigan_forward(W, mel[:1, :, :80])
     assert_close(y[:1, :, :25 * 256].cpu(), ref[:, :, :25 * 256], TOL, "full-size head vs oracle on a truncated input")
+
+
+def test_get_vocoder_and_vocoder_infer(mg, manifest, tmp_path):
+    """utils/model.py:74-126: checkpoint round trip through get_vocoder (weights_only load, remove_weight_norm) and
+    the int16 conversion / length cropping of vocoder_infer."""
+    import json
+    g = golden("hifigan")
+    G = _seeded_generator(mg, manifest, g)
+    ck = tmp_path / "generator_LJSpeech.pth.tar"
+    torch.save({"generator": {k: v.cpu() for k, v in G.state_dict().items()}}, ck)
+    cfg = tmp_path / "config.json"
+    cfg.write_text(json.dumps(R.HIFIGAN_V1))
+    mc = {"vocoder": {"model": "HiFi-GAN", "speaker": "LJSpeech"}}
+    voc = mg.vocoder.get_vocoder(mc, "cuda", config_path=str(cfg), checkpoint_path=str(ck))
+    assert "conv_pre.weight" in voc.state_dict() and not voc.training
+    mel = torch.from_numpy(g["mel"]).cuda()
+    pre = {"preprocessing": {"audio": {"max_wav_value": 32768.0}}}
+    wavs = mg.vocoder.vocoder_infer(mel, voc, mc, pre, lengths=[3000, 1234])
+    ref = (g["wav"][:, 0] * 32768.0).astype("int16")
+    assert [w.dtype.name for w in wavs] == ["int16", "int16"] and [len(w) for w in wavs] == [3000, 1234]
+    for w, r in zip(wavs, ref):
+        assert np.abs(w.astype(np.int32) - r[:len(w)].astype(np.int32)).max() <= 1     # fp32 rounding at .0 boundaries
+    with pytest.raises(NotImplementedError):
+        mg.vocoder.get_vocoder({"vocoder": {"model": "MelGAN", "speaker": "LJSpeech"}}, "cuda")
