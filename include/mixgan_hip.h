@@ -76,8 +76,8 @@ int mg_conv_pack_at(const float *w, float *packed, int Co, int Ci, int K, int mo
 /* Weight gradient of the same convolution (autograd of nn.Conv1d / nn.Linear weights):
  *   dw[co,ci,k] (+)= alpha * sum_{b,l} dy[b,co,l] * (x[b,ci,l*stride+k-pad] + x_vec[b,ci])
  * dy [B,Co,Ldy], x [B,Ci,Lx], dw [Co,Ci,K]; scratch: mg_conv1d_wgrad_scratch_floats() floats
- * (zeroed by the call; partial tiles are combined there with fp32 atomics, so the summation order
- * over frames is not fixed run to run). */
+ * (per-split partial tiles, at most 512 x 128 x 128 floats = 33.5 MB; written then summed in a fixed order, so
+ * the result is reproducible run to run; needs no initialisation). */
 size_t mg_conv1d_wgrad_scratch_floats(int Co, int Ci, int K);
 int mg_conv1d_wgrad(const float *dy, const float *x, const float *x_vec, float *dw, float *scratch,
                     int B, int Co, int Ci, int Ldy, int Lx, int K, int stride, int pad, float alpha,

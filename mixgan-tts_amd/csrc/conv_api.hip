@@ -168,7 +168,11 @@ extern "C" int mg_conv1d_fwd(const float *in, const float *in_vec, const float *
 // ---------------------------------------------------------------------------------------------
 // weight gradient + row sums (bias gradients, per-sample channel sums)
 // ---------------------------------------------------------------------------------------------
-extern "C" size_t mg_conv1d_wgrad_scratch_floats(int Co, int Ci, int K) { return (size_t)Co * Ci * K; }
+extern "C" size_t mg_conv1d_wgrad_scratch_floats(int Co, int Ci, int K)
+{
+    if (Co <= 0 || Ci <= 0 || K <= 0) return 0;
+    return wgrad_scratch_floats(Co, Ci, K);
+}
 
 extern "C" int mg_conv1d_wgrad_strided(const float *dy, long dy_bs, const float *x, long x_bs, const float *x_vec,
                                        float *dw, float *scratch, int B, int Co, int Ci, int Ldy, int Lx, int K,

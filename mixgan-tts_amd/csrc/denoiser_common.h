@@ -165,9 +165,15 @@ static inline DenBws den_bws(const mg_denoiser_dims *d, int B, int L)
     w.dh_all = take(NL * act);
     w.dy = take(act);
     w.dx0 = take(act);
-    size_t sc = 3 * 2 * C * C;
-    if (NL * C * H > sc) sc = NL * C * H;
-    if (C * M > sc) sc = C * M;
+    // partial-tile scratch of the largest weight gradient (mg_conv1d_wgrad_scratch_floats of each shape run by
+    // mg_denoiser_bwd: out 1x1, k=3, cond 1x1 of all layers at once, input / skip / output projections)
+    size_t sc = 0;
+    const int c = (int)C, h = (int)H, m = (int)M, nl = (int)NL;
+    const int shapes[6][3] = {{2 * c, c, 3}, {2 * c, c, 1}, {nl * c, h, 1}, {c, m, 1}, {c, c, 1}, {m, c, 1}};
+    for (const auto &sh : shapes) {
+        const size_t need = mg_conv1d_wgrad_scratch_floats(sh[0], sh[1], sh[2]);
+        if (need > sc) sc = need;
+    }
     w.scratch = take(sc);
     w.dd_all = take(NL * B * C);
     w.dhv_all = take(NL * B * C);

@@ -7,10 +7,11 @@
 // of one tap and walks 64-frame chunks of the (batch, frame) axis; chunk tiles are staged in LDS
 // with an odd row stride (65) so that the 32 lanes of an MFMA fragment -- 32 different rows, same
 // column -- hit 32 different banks.  The frame axis is split across `nsplit` workgroups per tile
-// (the output is tiny compared with the reduction: 393k outputs vs 16k frames) and partial tiles
-// are combined with fp32 atomics into a tap-major scratch [K][Co][Ci] whose rows are contiguous in
-// ci (256-byte atomic wave-instructions, the full-rate shape of MI355X_MICROARCH.md "Global float
-// atomics"); a finalize kernel writes the [Co, Ci, K] parameter layout.
+// (the output is tiny compared with the reduction: 393k outputs vs 16k frames); every split writes its
+// partial tile with plain 256-byte row stores into scratch [nsplit][K][Co][Ci] and the finalize kernel
+// sums the splits in a fixed order while it transposes to the [Co, Ci, K] parameter layout.  (The first
+// version combined the partials with fp32 atomics into one [K][Co][Ci] buffer: 8.4 M atomics per launch,
+// 15-30 us of a 60-100 us kernel, a memset in front, and a summation order that changed run to run.)
 #pragma once
 #include "common.h"
 
@@ -22,7 +23,7 @@ struct WgradArgs {
     const float *dy;    // [B, Co, Ldy] (batch stride dy_bs, row stride Ldy)
     const float *x;     // [B, Ci, Lx]  (batch stride x_bs,  row stride Lx)
     const float *xvec;  // optional [B, Ci]
-    float *scratch;     // [K][Co][Ci]
+    float *scratch;     // [nsplit][K][Co][Ci] partial sums
     long dy_bs, x_bs;
     int B, Co, Ci, Ldy, Lx, K, stride, pad;
     int chunks_per_b, nchunks, nsplit, ci_tiles;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a)
     }
 
     // acc[i][j][r]: co = co0 + wm*64 + i*32 + 8*(r>>2) + 4*hh + (r&3),  ci = ci0 + wn*64 + j*32 + c32
-    float *dst = a.scratch + (size_t)tap * a.Co * a.Ci;
+    float *dst = a.scratch + ((size_t)split * a.K + tap) * a.Co * a.Ci;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -183,22 +184,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int ci = ci0 + wn * 64 + j * 32 + c32;
-                if (ci < a.Ci) atomicAdd(dst + (size_t)co * a.Ci + ci, acc[i][j][r]);
+                if (ci < a.Ci) dst[(size_t)co * a.Ci + ci] = acc[i][j][r];
             }
         }
 }
 
-// scratch [K][Co][Ci] -> dw [Co][Ci][K] (= or +=), scaled
+// scratch [nsplit][K][Co][Ci] -> dw [Co][Ci][K] (= or +=), scaled; splits summed in index order
 __global__ void wgrad_finalize_kernel(const float *__restrict__ scratch, float *__restrict__ dw, int Co, int Ci, int K,
-                                      float alpha, int accumulate)
+                                      int nsplit, float alpha, int accumulate)
 {
     const size_t n = (size_t)Co * Ci * K;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int k = (int)(i % K);
-        const size_t cc = i / K;  // co*Ci + ci
-        const float v = alpha * scratch[(size_t)k * Co * Ci + cc];
-        dw[i] = accumulate ? dw[i] + v : v;
+        // thread <-> scratch element (k, co, ci): coalesced reads of every split; the [Co][Ci][K] write is strided by K
+        const size_t cc = i % ((size_t)Co * Ci);
+        const int k = (int)(i / ((size_t)Co * Ci));
+        float v = 0.f;
+        for (int s = 0; s < nsplit; ++s) v += scratch[(size_t)s * n + i];
+        v *= alpha;
+        float *o = dw + cc * K + k;
+        *o = accumulate ? *o + v : v;
     }
+}
+
+// number of frame splits for a [Co, Ci, K] gradient: two workgroups per CU are resident (66.5 KB LDS each), keep
+// the grid within ONE round of 512 workgroups -- 560 workgroups take two rounds, i.e. twice the time of 504
+static inline int wgrad_nsplit(int Co, int Ci, int K)
+{
+    const int tiles = mg_cdiv(Co, 128) * mg_cdiv(Ci, 128) * K;
+    const int n = 512 / tiles;
+    return n < 1 ? 1 : n;
+}
+static inline size_t wgrad_scratch_floats(int Co, int Ci, int K)
+{
+    return (size_t)wgrad_nsplit(Co, Ci, K) * Co * Ci * K;
 }
 
 struct WgradShape {
@@ -228,16 +246,10 @@ static int wgrad_launch(const WgradShape &s, const float *dy, const float *x, co
     a.chunks_per_b = mg_cdiv(s.Ldy, WG_FT);
     a.nchunks = a.chunks_per_b * s.B;
     a.ci_tiles = mg_cdiv(s.Ci, 128);
-    const int tiles = mg_cdiv(s.Co, 128) * a.ci_tiles * s.K;
-    // two workgroups per CU are resident (66.5 KB LDS each): keep the grid within ONE round of 512
-    // workgroups -- 560 workgroups take two rounds, i.e. twice the time of 504
-    int nsplit = 512 / tiles;
+    int nsplit = wgrad_nsplit(s.Co, s.Ci, s.K);
     if (nsplit > a.nchunks) nsplit = a.nchunks;
-    if (nsplit < 1) nsplit = 1;
     a.nsplit = nsplit;
     const size_t n = (size_t)s.Co * s.Ci * s.K;
-    hipError_t e = hipMemsetAsync(scratch, 0, n * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
     dim3 grid(nsplit, mg_cdiv(s.Co, 128) * a.ci_tiles, s.K);
     const bool vec = s.stride == 1 && !xvec && (s.Ldy % 4 == 0) && (s.Lx % 4 == 0) && (a.dy_bs % 4 == 0) &&
                      (a.x_bs % 4 == 0) && ((((uintptr_t)dy | (uintptr_t)x) & 15) == 0) && s.Ldy >= 4 && s.Lx >= 4;
@@ -245,7 +257,7 @@ static int wgrad_launch(const WgradShape &s, const float *dy, const float *x, co
     else hipLaunchKernelGGL(wgrad_mfma_kernel<false>, grid, dim3(256), 0, st, a);
     MG_LAUNCH_CHECK();
     const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, st, scratch, dw, s.Co, s.Ci, s.K, alpha,
+    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, st, scratch, dw, s.Co, s.Ci, s.K, nsplit, alpha,
                        accumulate);
     MG_LAUNCH_CHECK();
     return MG_OK;
