@@ -5,70 +5,14 @@
 // ---------------------------------------------------------------------------------------------
 // pack: [Co, Ci, K] fp32 -> Wp[mb][q][lane][e]  (layout: conv_mfma.h header)
 // ---------------------------------------------------------------------------------------------
-__global__ void pack_conv_kernel(const float *__restrict__ w, float *__restrict__ wp, int Co, int Ci, int K, int CK,
-                                 int CiP, int MB, int mode, int q0, int Qtot, int u)
+__global__ void pack_conv_kernel(const float *__restrict__ w, float *__restrict__ wp, PackDesc d)
 {
-    const int Q = CiP * K / 8;
-    const size_t total = (size_t)MB * Q * 256;
+    const size_t total = (size_t)d.MB * (d.CiP * d.K / 8) * 256;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int e = (int)(idx & 3);
-        const int lane = (int)((idx >> 2) & 63);
-        const size_t gq = idx >> 8;
-        const int q = (int)(gq % Q);
-        const int mb = (int)(gq / Q);
-        const int qc = K * (CK / 8);
-        const int chunk = q / qc;
-        const int rem = q - chunk * qc;
-        const int tap = rem / (CK / 8);
-        const int g = rem - tap * (CK / 8);
-        const int ci = chunk * CK + g * 8 + 2 * e + (lane >> 5);
-        const int r = lane & 31;
-        float v = 0.f;
-        if (mode == MG_PACK_PLAIN) {
-            const int row = mb * 32 + r;
-            if (row < Co && ci < Ci) v = w[((size_t)row * Ci + ci) * K + tap];
-        } else if (mode == MG_PACK_GATE) {
-            const int half = mb & 1, rr = (mb >> 1) * 32 + r;
-            if (rr < Co / 2 && ci < Ci) v = w[((size_t)(half * (Co / 2) + rr) * Ci + ci) * K + tap];
-        } else if (mode == MG_PACK_TPOSE) {
-            // ConvTranspose1d weight [Ci, Co', 2u] (stride u, padding u/2) as the 3-tap polyphase GEMM:
-            // row = co*u + phase; output u*m + phase reads x[m + c0] with tap rho and x[m + c0 - 1] with
-            // tap rho + u, where rho = (phase + u/2) % u, c0 = (phase + u/2) / u; here `Co` = Co' * u.
-            const int row = mb * 32 + r;
-            if (row < Co && ci < Ci) {
-                const int co = row / u, ph = row - co * u;
-                const int rho = (ph + u / 2) % u, c0 = (ph + u / 2) / u;
-                const int t = tap == c0 + 1 ? rho : (tap == c0 ? rho + u : -1);
-                if (t >= 0) v = w[((size_t)ci * (Co / u) + co) * (2 * u) + t];
-            }
-        } else {  // MG_PACK_DGRAD: rows = source Ci, reduction = source Co, taps flipped
-            const int row = mb * 32 + r;
-            if (row < Ci && ci < Co) v = w[((size_t)ci * Ci + row) * K + (K - 1 - tap)];
-        }
-        wp[(((size_t)mb * Qtot + q0 + q) << 8) + (idx & 255)] = v;
+        size_t dst;
+        const float v = mg_pack_element(w, d, idx, &dst);
+        wp[dst] = v;
     }
-}
-
-static int pack_dims(int Co, int Ci, int K, int mode, int *Mrows, int *Kin, int *MB)
-{
-    if (Co <= 0 || Ci <= 0 || !(K == 1 || K == 3 || K == 4 || K == 5 || K == 7 || K == 9 || K == 11 || K == 16))
-        return MG_ERR_SHAPE;
-    if (mode == MG_PACK_PLAIN) {
-        *Mrows = Co;
-        *Kin = Ci;
-        *MB = mg_conv_mblocks(Co);
-    } else if (mode == MG_PACK_GATE) {
-        if (Co % 2) return MG_ERR_SHAPE;
-        *Mrows = Co;
-        *Kin = Ci;
-        *MB = mg_round_up(2 * mg_cdiv(Co / 2, 32), 4);
-    } else if (mode == MG_PACK_DGRAD) {
-        *Mrows = Ci;
-        *Kin = Co;
-        *MB = mg_conv_mblocks(Ci);
-    } else
-        return MG_ERR_ARG;
-    return MG_OK;
 }
 
 extern "C" size_t mg_conv_packed_floats(int Co, int Ci, int K, int mode)
@@ -88,14 +32,11 @@ extern "C" int mg_conv_pack_at(const float *w, float *packed, int Co, int Ci, in
     if (!w || !packed) return MG_ERR_ARG;
     int Mrows, Kin, MB;
     MG_TRY(pack_dims(Co, Ci, K, mode, &Mrows, &Kin, &MB));
-    const int CK = mg_conv_ck(K);
-    const int CiP = mg_round_up(Kin, CK);
-    const int Q = CiP * K / 8;
-    if (q0 < 0 || q0 + Q > Qtot) return MG_ERR_SHAPE;
-    const size_t total = (size_t)MB * Q * 256;
+    PackDesc pd;
+    size_t total;
+    MG_TRY(mg_pack_desc(Co, Ci, K, mode, q0, Qtot, &pd, &total));
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(pack_conv_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Co, Ci, K, CK, CiP,
-                       MB, mode, q0, Qtot, 0);
+    hipLaunchKernelGGL(pack_conv_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, pd);
     MG_LAUNCH_CHECK();
     return MG_OK;
 }
@@ -125,8 +66,8 @@ extern "C" int mg_conv_transpose_pack(const float *w, float *packed, int Ci, int
     const int CK = mg_conv_ck(3), CiP = mg_round_up(Ci, CK), MB = mg_conv_mblocks(Co * u), Q = CiP * 3 / 8;
     const size_t total = (size_t)MB * Q * 256;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(pack_conv_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, Co * u, Ci, 3, CK,
-                       CiP, MB, MG_PACK_TPOSE, 0, Q, u);
+    const PackDesc pd{Co * u, Ci, 3, CK, CiP, MB, MG_PACK_TPOSE, 0, Q, u};
+    hipLaunchKernelGGL(pack_conv_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, pd);
     MG_LAUNCH_CHECK();
     return MG_OK;
 }

@@ -36,6 +36,54 @@ struct ConvArgs {
     float in_slope;       // leaky-ReLU slope applied to the input samples while staging (1 = identity)
 };
 
+// One element of the packed weight stream (layout above): destination index `idx` inside a [MB][Q][64][4] block
+// -> value, and the float offset it is stored at when the block is a q-slice [q0, q0 + Q) of a wider stream.
+// Shared by pack_conv_kernel (conv_api.hip) and the single-launch table pack of mg_denoiser_pack.
+struct PackDesc {
+    int Co, Ci, K, CK, CiP, MB, mode, q0, Qtot, u;
+};
+__device__ __forceinline__ float mg_pack_element(const float *__restrict__ w, const PackDesc &d, size_t idx, size_t *dst)
+{
+    const int Q = d.CiP * d.K / 8;
+    const int e = (int)(idx & 3);
+    const int lane = (int)((idx >> 2) & 63);
+    const size_t gq = idx >> 8;
+    const int q = (int)(gq % Q);
+    const int mb = (int)(gq / Q);
+    const int qc = d.K * (d.CK / 8);
+    const int chunk = q / qc;
+    const int rem = q - chunk * qc;
+    const int tap = rem / (d.CK / 8);
+    const int g = rem - tap * (d.CK / 8);
+    const int ci = chunk * d.CK + g * 8 + 2 * e + (lane >> 5);
+    const int r = lane & 31;
+    const int Co = d.Co, Ci = d.Ci, K = d.K;
+    float v = 0.f;
+    if (d.mode == MG_PACK_PLAIN) {
+        const int row = mb * 32 + r;
+        if (row < Co && ci < Ci) v = w[((size_t)row * Ci + ci) * K + tap];
+    } else if (d.mode == MG_PACK_GATE) {
+        const int half = mb & 1, rr = (mb >> 1) * 32 + r;
+        if (rr < Co / 2 && ci < Ci) v = w[((size_t)(half * (Co / 2) + rr) * Ci + ci) * K + tap];
+    } else if (d.mode == MG_PACK_TPOSE) {
+        // ConvTranspose1d weight [Ci, Co', 2u] (stride u, padding u/2) as the 3-tap polyphase GEMM:
+        // row = co*u + phase; output u*m + phase reads x[m + c0] with tap rho and x[m + c0 - 1] with
+        // tap rho + u, where rho = (phase + u/2) % u, c0 = (phase + u/2) / u; here `Co` = Co' * u.
+        const int row = mb * 32 + r, u = d.u;
+        if (row < Co && ci < Ci) {
+            const int co = row / u, ph = row - co * u;
+            const int rho = (ph + u / 2) % u, c0 = (ph + u / 2) / u;
+            const int t = tap == c0 + 1 ? rho : (tap == c0 ? rho + u : -1);
+            if (t >= 0) v = w[((size_t)ci * (Co / u) + co) * (2 * u) + t];
+        }
+    } else {  // MG_PACK_DGRAD: rows = source Ci, reduction = source Co, taps flipped
+        const int row = mb * 32 + r;
+        if (row < Ci && ci < Co) v = w[((size_t)ci * Ci + row) * K + (K - 1 - tap)];
+    }
+    *dst = (((size_t)mb * d.Qtot + d.q0 + q) << 8) + (idx & 255);
+    return v;
+}
+
 // number of k-groups (8 channels x 1 tap) per 32-row block
 static inline int mg_conv_qcount(int CiP, int K) { return CiP * K / 8; }
 static inline int mg_conv_ck(int K) { return K <= 3 ? 32 : 16; }
@@ -436,3 +484,46 @@ static int conv_launch(const ConvShape &s, const float *in, const float *in_vec,
 
 // number of 32-row blocks the packed form holds (padded to the workgroup M tile)
 static inline int mg_conv_mblocks(int Mrows) { return Mrows > 64 ? mg_round_up(Mrows, 128) / 32 : 2; }
+
+// Row / reduction bookkeeping of a pack: GEMM rows, reduction channels and 32-row blocks held by the packed form.
+static inline int pack_dims(int Co, int Ci, int K, int mode, int *Mrows, int *Kin, int *MB)
+{
+    if (Co <= 0 || Ci <= 0 || !(K == 1 || K == 3 || K == 4 || K == 5 || K == 7 || K == 9 || K == 11 || K == 16))
+        return MG_ERR_SHAPE;
+    if (mode == MG_PACK_PLAIN) {
+        *Mrows = Co;
+        *Kin = Ci;
+        *MB = mg_conv_mblocks(Co);
+    } else if (mode == MG_PACK_GATE) {
+        if (Co % 2) return MG_ERR_SHAPE;
+        *Mrows = Co;
+        *Kin = Ci;
+        *MB = mg_round_up(2 * mg_cdiv(Co / 2, 32), 4);
+    } else if (mode == MG_PACK_DGRAD) {
+        *Mrows = Ci;
+        *Kin = Co;
+        *MB = mg_conv_mblocks(Ci);
+    } else
+        return MG_ERR_ARG;
+    return MG_OK;
+}
+
+// PackDesc + element count of packing [Co, Ci, K] as k-groups [q0, q0 + Q) of a stream holding Qtot per block
+// (Qtot <= 0: a stand-alone pack).
+static inline int mg_pack_desc(int Co, int Ci, int K, int mode, int q0, int Qtot, PackDesc *pd, size_t *total)
+{
+    int Mrows, Kin, MB;
+    const int rc = pack_dims(Co, Ci, K, mode, &Mrows, &Kin, &MB);
+    if (rc != MG_OK) return rc;
+    const int CK = mg_conv_ck(K);
+    const int CiP = mg_round_up(Kin, CK);
+    const int Q = CiP * K / 8;
+    if (Qtot <= 0) {
+        q0 = 0;
+        Qtot = Q;
+    }
+    if (q0 < 0 || q0 + Q > Qtot) return MG_ERR_SHAPE;
+    *pd = PackDesc{Co, Ci, K, CK, CiP, MB, mode, q0, Qtot, 0};
+    *total = (size_t)MB * Q * 256;
+    return MG_OK;
+}

@@ -149,6 +149,51 @@ static int copy_d2d(float *dst, const float *src, size_t n, hipStream_t st)
     return e == hipSuccess ? MG_OK : (int)e;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Packing.  A training step repacks every weight after the optimizer step: issued one matrix at a time that is
+// ~230 tiny launches and device-to-device copies (0.5 ms + 0.5 ms of a 17 ms step).  Here the whole job is a table
+// of (source pointer, destination offset, pack descriptor) entries, uploaded into a reserved slice of the packed
+// buffer and executed by ONE kernel; a workgroup finds its entry by the prefix sums of the per-entry block counts.
+// ---------------------------------------------------------------------------------------------
+struct PackJob {
+    const float *src;
+    unsigned long long dst;     // float offset into `packed`
+    unsigned long long total;   // elements to produce
+    PackDesc d;                 // d.mode < 0: plain copy of `total` floats
+    unsigned first_block, nblocks;
+};
+
+__global__ __launch_bounds__(256) void pack_table_kernel(const PackJob *__restrict__ jobs, int njobs,
+                                                         float *__restrict__ packed)
+{
+    __shared__ int which;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = njobs - 1;   // last job whose first_block <= blockIdx.x
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].first_block <= blockIdx.x) lo = mid;
+            else hi = mid - 1;
+        }
+        which = lo;
+    }
+    __syncthreads();
+    const PackJob j = jobs[which];
+    const size_t stride = (size_t)j.nblocks * 256;
+    float *out = packed + j.dst;
+    for (size_t idx = (size_t)(blockIdx.x - j.first_block) * 256 + threadIdx.x; idx < j.total; idx += stride) {
+        if (j.d.mode < 0) {
+            out[idx] = j.src[idx];
+        } else {
+            size_t dst;
+            const float v = mg_pack_element(j.src, j.d, idx, &dst);
+            out[dst] = v;
+        }
+    }
+}
+
+#define MG_DEN_MAX_JOBS 512
+static_assert(sizeof(PackJob) <= 96, "den_layout reserves 96 bytes per pack job");
+
 extern "C" int mg_denoiser_pack(const mg_denoiser_dims *d, const float *const *w, const float *freq, float *packed,
                                 int flags, void *stream)
 {
@@ -160,42 +205,83 @@ extern "C" int mg_denoiser_pack(const mg_denoiser_dims *d, const float *const *w
     const DenLayout o = den_layout(d, flags);
     for (int i = 0; i < MG_DEN_HEAD_PTRS; ++i)
         if (!w[i]) return MG_ERR_ARG;
-    MG_TRY(copy_d2d(packed + o.freq, freq, C / 2, st));
-    MG_TRY(mg_conv_pack(w[0], packed + o.in_w, C, M, 1, MG_PACK_PLAIN, stream));
-    MG_TRY(copy_d2d(packed + o.in_b, w[1], C, st));
-    MG_TRY(copy_d2d(packed + o.mlp0, w[2], (size_t)4 * C * C, st));
-    MG_TRY(copy_d2d(packed + o.mlp2, w[3], (size_t)4 * C * C, st));
-    MG_TRY(mg_conv_pack(w[4], packed + o.skip_w, C, C, 1, MG_PACK_PLAIN, stream));
-    MG_TRY(copy_d2d(packed + o.skip_b, w[5], C, st));
-    MG_TRY(mg_conv_pack(w[6], packed + o.out_w, M, C, 1, MG_PACK_PLAIN, stream));
-    MG_TRY(copy_d2d(packed + o.out_b, w[7], M, st));
+
+    static thread_local PackJob jobs[MG_DEN_MAX_JOBS];
+    int n = 0;
+    unsigned blocks = 0;
+    int rc = MG_OK;
+    auto push = [&](const float *src, size_t dst, size_t total, const PackDesc &pd) {
+        if (!src || n >= MG_DEN_MAX_JOBS) {
+            rc = MG_ERR_ARG;
+            return;
+        }
+        unsigned nb = (unsigned)((total + 255) / 256);
+        if (nb > 512) nb = 512;   // grid-stride inside the job beyond that
+        if (nb < 1) nb = 1;
+        jobs[n++] = PackJob{src, dst, total, pd, blocks, nb};
+        blocks += nb;
+    };
+    auto copy = [&](size_t dst, const float *src, size_t count) {
+        PackDesc pd{};
+        pd.mode = -1;
+        push(src, dst, count, pd);
+    };
+    auto pack = [&](const float *src, size_t dst, int Co, int Ci, int K, int mode, int q0 = 0, int Qtot = 0) {
+        PackDesc pd;
+        size_t total;
+        const int r = mg_pack_desc(Co, Ci, K, mode, q0, Qtot, &pd, &total);
+        if (r != MG_OK) {
+            rc = r;
+            return;
+        }
+        push(src, dst, total, pd);
+    };
+    copy(o.freq, freq, C / 2);
+    pack(w[0], o.in_w, C, M, 1, MG_PACK_PLAIN);
+    copy(o.in_b, w[1], C);
+    copy(o.mlp0, w[2], (size_t)4 * C * C);
+    copy(o.mlp2, w[3], (size_t)4 * C * C);
+    pack(w[4], o.skip_w, C, C, 1, MG_PACK_PLAIN);
+    copy(o.skip_b, w[5], C);
+    pack(w[6], o.out_w, M, C, 1, MG_PACK_PLAIN);
+    copy(o.out_b, w[7], M);
     for (int l = 0; l < d->n_layers; ++l) {
         const float *const *lw = w + MG_DEN_HEAD_PTRS + (size_t)l * MG_DEN_LAYER_PTRS;
-        float *lp = packed + o.layers + (size_t)l * o.layer_stride;
+        const size_t lp = o.layers + (size_t)l * o.layer_stride;
         for (int j = 0; j < 7; ++j)
             if (!lw[j]) return MG_ERR_ARG;
-        MG_TRY(mg_conv_pack(lw[0], lp + o.l_w3, 2 * C, C, 3, MG_PACK_GATE, stream));
-        MG_TRY(copy_d2d(lp + o.l_b3, lw[1], 2 * C, st));
-        MG_TRY(copy_d2d(lp + o.l_wd, lw[2], (size_t)C * C, st));
-        MG_TRY(mg_conv_pack(lw[3], lp + o.l_wc, C, H, 1, MG_PACK_PLAIN, stream));
-        MG_TRY(copy_d2d(lp + o.l_bc, lw[4], C, st));
-        MG_TRY(mg_conv_pack(lw[5], lp + o.l_wo, 2 * C, C, 1, MG_PACK_PLAIN, stream));
-        MG_TRY(copy_d2d(lp + o.l_bo, lw[6], 2 * C, st));
-        if (d->multi_speaker) MG_TRY(copy_d2d(lp + o.l_wp, lw[7], (size_t)C * H, st));
+        pack(lw[0], lp + o.l_w3, 2 * C, C, 3, MG_PACK_GATE);
+        copy(lp + o.l_b3, lw[1], 2 * C);
+        copy(lp + o.l_wd, lw[2], (size_t)C * C);
+        pack(lw[3], lp + o.l_wc, C, H, 1, MG_PACK_PLAIN);
+        copy(lp + o.l_bc, lw[4], C);
+        pack(lw[5], lp + o.l_wo, 2 * C, C, 1, MG_PACK_PLAIN);
+        copy(lp + o.l_bo, lw[6], 2 * C);
+        if (d->multi_speaker) copy(lp + o.l_wp, lw[7], (size_t)C * H);
     }
     if (with_backward) {
         // data-gradient (transposed, tap-flipped) packs for mg_denoiser_bwd
-        MG_TRY(mg_conv_pack(w[0], packed + o.in_wT, C, M, 1, MG_PACK_DGRAD, stream));
-        MG_TRY(mg_conv_pack(w[4], packed + o.skip_wT, C, C, 1, MG_PACK_DGRAD, stream));
-        MG_TRY(mg_conv_pack(w[6], packed + o.out_wT, M, C, 1, MG_PACK_DGRAD, stream));
+        pack(w[0], o.in_wT, C, M, 1, MG_PACK_DGRAD);
+        pack(w[4], o.skip_wT, C, C, 1, MG_PACK_DGRAD);
+        pack(w[6], o.out_wT, M, C, 1, MG_PACK_DGRAD);
         const int Qtot = d->n_layers * C / 8;
         for (int l = 0; l < d->n_layers; ++l) {
             const float *const *lw = w + MG_DEN_HEAD_PTRS + (size_t)l * MG_DEN_LAYER_PTRS;
-            float *bp = packed + o.blayers + (size_t)l * o.blayer_stride;
-            MG_TRY(mg_conv_pack_at(lw[3], packed + o.wc_allT, C, H, 1, MG_PACK_DGRAD, l * (C / 8), Qtot, stream));
-            MG_TRY(mg_conv_pack(lw[0], bp + o.bl_w3T, 2 * C, C, 3, MG_PACK_DGRAD, stream));
-            MG_TRY(mg_conv_pack(lw[5], bp + o.bl_woT, 2 * C, C, 1, MG_PACK_DGRAD, stream));
+            const size_t bp = o.blayers + (size_t)l * o.blayer_stride;
+            pack(lw[3], o.wc_allT, C, H, 1, MG_PACK_DGRAD, l * (C / 8), Qtot);
+            pack(lw[0], bp + o.bl_w3T, 2 * C, C, 3, MG_PACK_DGRAD);
+            pack(lw[5], bp + o.bl_woT, 2 * C, C, 1, MG_PACK_DGRAD);
         }
+    }
+    if (rc != MG_OK) return rc;
+    {
+        // the table travels in the reserved tail of the packed buffer (host memory is pageable: the runtime stages
+        // the 30 KB copy, after which `jobs` may be reused)
+        PackJob *dev_jobs = reinterpret_cast<PackJob *>(packed + o.jobs);
+        hipError_t e = hipMemcpyAsync(dev_jobs, jobs, (size_t)n * sizeof(PackJob), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(pack_table_kernel, dim3(blocks), dim3(256), 0, st, dev_jobs, n, packed);
+        MG_LAUNCH_CHECK();
     }
     if (flags & MG_DEN_SPLIT) {
         if (C != RB_C || H != RB_C) return MG_ERR_SHAPE;

@@ -14,6 +14,7 @@ struct DenLayout {
     size_t bl_w3T, bl_woT;
     // split-bf16 section (resblock_split.h), present when flags & MG_DEN_SPLIT
     size_t slayers, slayer_stride, sl_wc, sl_w3, sl_wo;
+    size_t jobs;   // scratch slice for the pack job table (mg_denoiser_pack)
     size_t total;
 };
 
@@ -93,6 +94,10 @@ static inline DenLayout den_layout(const mg_denoiser_dims *d, int flags)
         o.slayer_stride = r;
         p += r * NL;
     }
+    // reserved for the job table of mg_denoiser_pack (512 entries x 96 B, 16-byte aligned)
+    p = mg_align_up(p, 64);
+    o.jobs = p;
+    p += 512 * 96 / 4;
     o.total = p;
     return o;
 }
