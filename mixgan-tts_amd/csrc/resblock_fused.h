@@ -78,13 +78,28 @@ struct ResArgs {
 // the weight float4s run 2 k-groups ahead (ring of 4), the B fragments one k-group ahead (double
 // buffer); each k-group's prefetches are issued at its top and pinned there with sched_barrier (left
 // alone, the scheduler sinks loads next to their use and the MFMAs wait on the round trip).
+#define RB_DIST 2   // weight prefetch distance in k-groups
+
+// The first RB_DIST weight k-groups of a GEMM phase, loaded early: issued before the previous phase's epilogue and
+// barrier (or, for GEMM 1, before the cond tile is staged) so that their L2 round trip is not exposed at the top
+// of the k-loop three times per layer.
+template <int NMB>
+__device__ __forceinline__ void rb_preload(f32x4 (&pre)[RB_DIST][NMB], const f32x4 *ap0, int qstride_mb)
+{
+#pragma unroll
+    for (int s = 0; s < RB_DIST; ++s)
+#pragma unroll
+        for (int i = 0; i < NMB; ++i) pre[s][i] = ap0[(size_t)i * qstride_mb + (size_t)s * 64];
+}
+
 template <int NMB, int NNB, int KW, int RS, int NCH = 8>
 __device__ __forceinline__ void rb_mfma_loop(f32x16 (&acc)[NMB][NNB], const f32x4 *ap0, int qstride_mb,
-                                             const float *__restrict__ tile, int bcol)
+                                             const float *__restrict__ tile, int bcol,
+                                             const f32x4 (&pre)[RB_DIST][NMB])
 {
     constexpr int TC = NCH * KW;     // (chunk, tap) pairs; 4 k-groups each
     constexpr int Q = TC * 4;
-    constexpr int DIST = 2;
+    constexpr int DIST = RB_DIST;
     const f32x4 *ap[NMB];
 #pragma unroll
     for (int i = 0; i < NMB; ++i) ap[i] = ap0 + (size_t)i * qstride_mb;
@@ -94,7 +109,7 @@ __device__ __forceinline__ void rb_mfma_loop(f32x16 (&acc)[NMB][NNB], const f32x
 #pragma unroll
     for (int s = 0; s < DIST; ++s)
 #pragma unroll
-        for (int i = 0; i < NMB; ++i) ring[s][i] = ap[i][(size_t)s * 64];
+        for (int i = 0; i < NMB; ++i) ring[s][i] = pre[s][i];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -152,6 +167,16 @@ __device__ __forceinline__ void rb_mfma_loop(f32x16 (&acc)[NMB][NNB], const f32x
     }
 }
 
+// same loop, first weight k-groups loaded at the call (head / tail kernels: one short GEMM each)
+template <int NMB, int NNB, int KW, int RS, int NCH = 8>
+__device__ __forceinline__ void rb_mfma_loop(f32x16 (&acc)[NMB][NNB], const f32x4 *ap0, int qstride_mb,
+                                             const float *__restrict__ tile, int bcol)
+{
+    f32x4 pre[RB_DIST][NMB];
+    rb_preload<NMB>(pre, ap0, qstride_mb);
+    rb_mfma_loop<NMB, NNB, KW, RS, NCH>(acc, ap0, qstride_mb, tile, bcol, pre);
+}
+
 template <bool VEC4, bool SAVE, int NTILE = 64>
 __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(ResArgs a)
 {
@@ -172,6 +197,12 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(ResArgs a)
     const int l0 = (blockIdx.x - b * a.tiles_per_b) * NTU;
     const int L = a.L;
     const size_t bbase = (size_t)b * RB_C * L;
+
+    const f32x4 *ap1 = reinterpret_cast<const f32x4 *>(a.wc) + (size_t)w * 32 * 64 + lane;
+    const f32x4 *ap2 = reinterpret_cast<const f32x4 *>(a.w3) + (size_t)(2 * w) * 96 * 64 + lane;
+    const f32x4 *ap3 = reinterpret_cast<const f32x4 *>(a.wo) + (size_t)(2 * w) * 32 * 64 + lane;
+    f32x4 pre1[RB_DIST][1];
+    rb_preload<1>(pre1, ap1, 0);
 
     // ---------------------------------------------------------------- stage cond tile -> LDS
     {
@@ -220,8 +251,9 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(ResArgs a)
         }
     }
     __syncthreads();
-    rb_mfma_loop<1, NB1, 1, RSC>(acc1, reinterpret_cast<const f32x4 *>(a.wc) + (size_t)w * 32 * 64 + lane, 0,
-                                 condT + hh * RSC, 3 + c32);
+    rb_mfma_loop<1, NB1, 1, RSC>(acc1, ap1, 0, condT + hh * RSC, 3 + c32, pre1);
+    f32x4 pre2[RB_DIST][2];
+    rb_preload<2>(pre2, ap2, 96 * 64);   // lands behind the h write-back and the barrier below
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = w * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
@@ -251,8 +283,9 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(ResArgs a)
         for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
-    rb_mfma_loop<2, NB, 3, RSH>(acc2, reinterpret_cast<const f32x4 *>(a.w3) + (size_t)(2 * w) * 96 * 64 + lane, 96 * 64,
-                                hT + hh * RSH, c32);
+    rb_mfma_loop<2, NB, 3, RSH>(acc2, ap2, 96 * 64, hT + hh * RSH, c32, pre2);
+    f32x4 pre3[RB_DIST][2];
+    rb_preload<2>(pre3, ap3, 32 * 64);   // lands behind the gate epilogue, the addend loads and the barrier
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int ch = w * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
@@ -308,8 +341,7 @@ __global__ __launch_bounds__(512, 2) void resblock_fused_kernel(ResArgs a)
         for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc3[i][j][r] = 0.f;
-    rb_mfma_loop<2, NB, 1, RSG>(acc3, reinterpret_cast<const f32x4 *>(a.wo) + (size_t)(2 * w) * 32 * 64 + lane, 32 * 64,
-                                gT + hh * RSG, c32);
+    rb_mfma_loop<2, NB, 1, RSG>(acc3, ap3, 32 * 64, gT + hh * RSG, c32, pre3);
     {
         const bool xrows = w < 4;
         float *dst = xrows ? a.x_out + bbase : a.skip + bbase;
