@@ -343,8 +343,40 @@ def attention_bench():
                           "f16_TFLOPs": round(fl / t16 / 1e12, 1), "max_abs_diff": err}), flush=True)
 
 
+def e2e_bench():
+    """Conditioner -> mel -> waveform on the HIP path (`synthesize.py` minus the out-of-scope text front-end and
+    linguistic encoder): naive model, T=4 sampling (hipGraph) + HiFi-GAN + int16 conversion, 1000-frame utterances."""
+    import types
+    from oracle import refmath as R   # only for the HiFi-GAN V1 config constants
+    dev = torch.device("cuda", 0)
+    d = tempfile.mkdtemp()
+    stats = write_stats(d, [-11.5] * 80, [2.0] * 80)
+    gd = mg.GaussianDiffusion(*hot_path_configs("naive", 4, stats_dir=stats))
+    seeded_(gd, 1)
+    gd = gd.to(dev).eval()
+    voc = mg.vocoder.Generator(types.SimpleNamespace(**R.HIFIGAN_V1)).to(dev).eval()
+    voc.remove_weight_norm()
+    mc = {"vocoder": {"model": "HiFi-GAN", "speaker": "LJSpeech"}}
+    pre = {"preprocessing": {"audio": {"max_wav_value": 32768.0}}}
+    for B, L in ((1, 1000), (16, 1000)):
+        cond = torch.randn(B, L, 256, device=dev)
+        pad = torch.zeros(B, L, dtype=torch.bool, device=dev)
+
+        def run():
+            with torch.no_grad():
+                mel = gd(None, cond, None, pad, None)[0]          # inference branch: T p_sample steps -> [B, L, 80]
+                return mg.vocoder.vocoder_infer(mel.transpose(1, 2).contiguous(), voc, mc, pre)
+        t = timeit(run, 2, 5)
+        audio = B * L * 256 / 22050.0
+        print(json.dumps({"config": "e2e cond -> mel (T=4) -> wav, B=%d, L=%d" % (B, L), "ms": round(t * 1e3, 2),
+                          "audio_s": round(audio, 1), "real_time_factor": round(t / audio, 5),
+                          "audio_seconds_per_s": round(audio / t, 1)}), flush=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "attention":
+    if len(sys.argv) > 1 and sys.argv[1] == "e2e":
+        e2e_bench()
+    elif len(sys.argv) > 1 and sys.argv[1] == "attention":
         attention_bench()
     elif len(sys.argv) > 1 and sys.argv[1] == "aux":
         aux_bench()
