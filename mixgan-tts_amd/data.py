@@ -162,15 +162,20 @@ class Dataset(torch.utils.data.Dataset):
         )
 
     def collate_fn(self, data):
-        """dataset.py:171-190: sort the group by text length (descending), cut into batch_size sub-batches."""
-        n = len(data)
-        idx_arr = np.argsort(-np.array([d["text"].shape[0] for d in data])) if self.sort else np.arange(n)
-        tail = idx_arr[len(idx_arr) - (len(idx_arr) % self.batch_size):]
-        idx_arr = idx_arr[: len(idx_arr) - (len(idx_arr) % self.batch_size)]
-        groups = idx_arr.reshape((-1, self.batch_size)).tolist()
-        if not self.drop_last and len(tail) > 0:
-            groups += [tail.tolist()]
-        return [self.reprocess(data, g) for g in groups]
+        """dataset.py:171-190: order the group by text length (longest first) when `sort`, cut it into consecutive
+        sub-batches of `batch_size`; a short remainder becomes a last sub-batch unless `drop_last`."""
+        order = list(range(len(data)))
+        if self.sort:
+            # np.argsort(-len) semantics: descending, and among equal lengths the order numpy's default
+            # (introsort, not stable) produces -- delegate to it so ties break exactly like the reference
+            order = np.argsort(-np.array([d["text"].shape[0] for d in data])).tolist()
+        bs = self.batch_size
+        n_full = len(order) // bs
+        cuts = [order[k * bs:(k + 1) * bs] for k in range(n_full)]
+        rest = order[n_full * bs:]
+        if rest and not self.drop_last:
+            cuts.append(rest)
+        return [self.reprocess(data, c) for c in cuts]
 
 
 class TextDataset(torch.utils.data.Dataset):
