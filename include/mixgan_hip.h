@@ -88,6 +88,15 @@ int mg_conv1d_wgrad_strided(const float *dy, long dy_bs, const float *x, long x_
                             float *dw, float *scratch, int B, int Co, int Ci, int Ldy, int Lx, int K,
                             int stride, int pad, float alpha, int accumulate, void *stream);
 
+/* G weight gradients of one shape in a single launch: group g uses dy + g*dy_gs, x + g*x_gs (a group stride of 0
+ * shares that operand) and writes dw + g*dw_gs (0 = Co*Ci*K).  mg_denoiser_bwd computes the gradients of all
+ * 20 residual layers' k=3 and output convolutions this way once their inputs are complete: with G*tiles >= 512
+ * workgroups no frame split is needed and the combine pass degenerates to the layout transpose. */
+size_t mg_conv1d_wgrad_grouped_scratch_floats(int Co, int Ci, int K, int G);
+int mg_conv1d_wgrad_grouped(const float *dy, long dy_bs, long dy_gs, const float *x, long x_bs, long x_gs, float *dw,
+                            long dw_gs, float *scratch, int G, int B, int Co, int Ci, int Ldy, int Lx, int K, int stride,
+                            int pad, float alpha, int accumulate, void *stream);
+
 /* Row sums of in [B,R,L] (batch stride in_bs floats, 0 = dense): bias gradients and per-sample
  * channel sums.  out_r[r] (+)= alpha*sum_{b,l} (may be NULL); out_br[b,r] = alpha*sum_l (may be NULL). */
 int mg_rowsum(const float *in, long in_bs, int B, int R, int L, float *out_r, float *out_br,
@@ -195,9 +204,11 @@ int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, const float 
  * forward's workspace of a save_for_backward call on the same inputs; `bwd_workspace` has
  * mg_denoiser_bwd_workspace_floats() floats.  g_out [B, M, L] is dL/d(out).
  * grads: pointer table in the order of mg_denoiser_pack's weight table; every non-NULL entry
- * receives dL/dW (overwritten, not accumulated).  The per-layer entries j=2 (diffusion_projection),
- * j=3/j=4 (conditioner_projection weight/bias) and j=7 (speaker_projection) must be slices of
- * one contiguous [n_layers, ...] buffer each (they are produced by one batched GEMM).
+ * receives dL/dW (overwritten, not accumulated).  Every per-layer entry (j=0/1 conv_layer weight/bias, j=2
+ * diffusion_projection, j=3/4 conditioner_projection weight/bias, j=5/6 output_projection weight/bias, j=7
+ * speaker_projection) must be the layer's slice of one contiguous [n_layers, ...] buffer: the layer loop only
+ * runs the two data-gradient GEMMs per layer and keeps their results (0.5 GB of the workspace at B=8, L=1000);
+ * all weight and bias gradients are then produced by a few launches grouped over the layer axis.
  * d_x_t [B,M,L], d_cond [B,H,L], d_spk [B,H] may be NULL when not needed. */
 size_t mg_denoiser_bwd_workspace_floats(const mg_denoiser_dims *d, int B, int L);
 int mg_denoiser_bwd(const mg_denoiser_dims *d, const float *packed, const float *g_out,

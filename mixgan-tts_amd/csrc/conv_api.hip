@@ -125,6 +125,22 @@ extern "C" int mg_conv1d_wgrad_strided(const float *dy, long dy_bs, const float 
     return wgrad_launch(s, dy, x, x_vec, dw, scratch, alpha, accumulate, (hipStream_t)stream);
 }
 
+extern "C" size_t mg_conv1d_wgrad_grouped_scratch_floats(int Co, int Ci, int K, int G)
+{
+    if (Co <= 0 || Ci <= 0 || K <= 0 || G <= 0) return 0;
+    return wgrad_scratch_floats(Co, Ci, K, G);
+}
+
+extern "C" int mg_conv1d_wgrad_grouped(const float *dy, long dy_bs, long dy_gs, const float *x, long x_bs, long x_gs,
+                                       float *dw, long dw_gs, float *scratch, int G, int B, int Co, int Ci, int Ldy, int Lx,
+                                       int K, int stride, int pad, float alpha, int accumulate, void *stream)
+{
+    if (!dy || !x || !dw || !scratch) return MG_ERR_ARG;
+    if (stride < 1 || pad < 0 || G < 1) return MG_ERR_SHAPE;
+    WgradShape s{B, Co, Ci, Ldy, Lx, K, stride, pad, dy_bs, x_bs, G, dy_gs, x_gs, dw_gs};
+    return wgrad_launch(s, dy, x, nullptr, dw, scratch, alpha, accumulate, (hipStream_t)stream);
+}
+
 extern "C" int mg_conv1d_wgrad(const float *dy, const float *x, const float *x_vec, float *dw, float *scratch, int B,
                                int Co, int Ci, int Ldy, int Lx, int K, int stride, int pad, float alpha,
                                int accumulate, void *stream)

@@ -14,10 +14,11 @@
 // ------------------------------------------------------------------------------------------ epilogues
 struct EpiGateBwd {
     struct Params {
-        float *dz;         // [B, 2C, L]
+        float *dz;         // [B, 2C, L] slice of dz_all (batch stride dz_bs)
         const float *sig;  // [B, C, L] sigmoid(gate) saved by the forward
         const float *tnh;  // [B, C, L] tanh(filter)
         int C;
+        long dz_bs;        // floats between batch elements of dz
     };
     template <int WM, int NNB>
     static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][NNB], int b, int mrow0, int l0w,
@@ -47,7 +48,7 @@ struct EpiGateBwd {
                     rok[r] = ch < p.C;
                     const int cc = rok[r] ? ch : p.C - 1;
                     const size_t so = ((size_t)b * p.C + cc) * Lout;
-                    zo[r] = ((size_t)b * 2 * p.C + cc) * Lout;
+                    zo[r] = (size_t)b * p.dz_bs + (size_t)cc * Lout;
 #pragma unroll
                     for (int j = 0; j < NNB; ++j) {
                         sv[r][j] = p.sig[so + lc[j]];
@@ -75,6 +76,8 @@ struct EpiDhBwd {
         long dh_bs;      // NL*C*L
         float *dout;     // [B, 2C, L]; rows < C hold dx_{l+1}/sqrt2 on entry, dx_l/sqrt2 on exit
         int C;
+        float *xsave;    // copy of the exit value into this layer's slot of dx_all (batch stride xsave_bs)
+        long xsave_bs;
     };
     template <int WM, int NNB>
     static __device__ __forceinline__ void run(const Params &p, f32x16 (&acc)[WM][NNB], int b, int mrow0, int l0w,
@@ -95,7 +98,7 @@ struct EpiDhBwd {
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 float xv[8][NNB];
-                size_t ho[8], xo[8];
+                size_t ho[8], xo[8], so[8];
                 bool rok[8];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
@@ -105,6 +108,7 @@ struct EpiDhBwd {
                     const int cc = rok[r] ? ch : p.C - 1;
                     ho[r] = (size_t)b * p.dh_bs + (size_t)cc * Lout;
                     xo[r] = ((size_t)b * 2 * p.C + cc) * Lout;
+                    so[r] = (size_t)b * p.xsave_bs + (size_t)cc * Lout;
 #pragma unroll
                     for (int j = 0; j < NNB; ++j) xv[r][j] = p.dout[xo[r] + lc[j]];
                 }
@@ -114,8 +118,10 @@ struct EpiDhBwd {
                     for (int j = 0; j < NNB; ++j) {
                         const float v = acc[i][j][half * 8 + r];
                         if (rok[r] && lok[j]) {
+                            const float nx = (v + xv[r][j]) * rs2;
                             p.dh[ho[r] + lc[j]] = v;
-                            p.dout[xo[r] + lc[j]] = (v + xv[r][j]) * rs2;
+                            p.dout[xo[r] + lc[j]] = nx;
+                            p.xsave[so[r] + lc[j]] = nx;
                         }
                     }
             }
@@ -133,6 +139,23 @@ static int wgrad_launch(const WgradShape &s, const float *dy, const float *x, co
 {
     return mg_conv1d_wgrad_strided(dy, s.dy_bs, x, s.x_bs, xvec, dw, scratch, s.B, s.Co, s.Ci, s.Ldy, s.Lx, s.K, s.stride,
                                    s.pad, alpha, accumulate, st);
+}
+
+static int wgrad_grouped(int G, const float *dy, long dy_bs, long dy_gs, const float *x, long x_bs, long x_gs, float *dw,
+                         long dw_gs, float *scratch, int B, int Co, int Ci, int L, int K, int pad, hipStream_t st)
+{
+    return mg_conv1d_wgrad_grouped(dy, dy_bs, dy_gs, x, x_bs, x_gs, dw, dw_gs, scratch, G, B, Co, Ci, L, L, K, 1, pad, 1.f,
+                                   0, st);
+}
+
+// out[l][0:C] = top[l*C + c], out[l][C:2C] = bottom[c]   (output-conv bias gradients of all layers)
+static __global__ void bias_scatter_kernel(const float *__restrict__ top, const float *__restrict__ bottom,
+                                           float *__restrict__ out, int NL, int C)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NL * 2 * C) return;
+    const int l = i / (2 * C), r = i - l * 2 * C;
+    out[i] = r < C ? top[l * C + r] : bottom[r - C];
 }
 
 static int rowsum(const float *in, long in_bs, int B, int R, int L, float *out_r, float *out_br, float alpha,
@@ -167,14 +190,20 @@ extern "C" int mg_denoiser_bwd(const mg_denoiser_dims *d, const float *packed, c
     auto LG = [&](int l, int j) { return lg0[(size_t)l * MG_DEN_LAYER_PTRS + j]; };
     // batched outputs must be contiguous across layers
     for (int l = 1; l < NL; ++l) {
+        if (LG(0, 0) && LG(l, 0) != LG(0, 0) + (size_t)l * 2 * C * C * 3) return MG_ERR_ARG;
+        if (LG(0, 1) && LG(l, 1) != LG(0, 1) + (size_t)l * 2 * C) return MG_ERR_ARG;
         if (LG(0, 2) && LG(l, 2) != LG(0, 2) + (size_t)l * C * C) return MG_ERR_ARG;
         if (LG(0, 3) && LG(l, 3) != LG(0, 3) + (size_t)l * C * H) return MG_ERR_ARG;
         if (LG(0, 4) && LG(l, 4) != LG(0, 4) + (size_t)l * C) return MG_ERR_ARG;
+        if (LG(0, 5) && LG(l, 5) != LG(0, 5) + (size_t)l * 2 * C * C) return MG_ERR_ARG;
+        if (LG(0, 6) && LG(l, 6) != LG(0, 6) + (size_t)l * 2 * C) return MG_ERR_ARG;
         if (d->multi_speaker && LG(0, 7) && LG(l, 7) != LG(0, 7) + (size_t)l * C * H) return MG_ERR_ARG;
     }
     const size_t CL = (size_t)C * L;
-    float *dout = bws + bw.dout, *dz = bws + bw.dz, *dh_all = bws + bw.dh_all, *dy = bws + bw.dy;
+    float *dout = bws + bw.dout, *dz_all = bws + bw.dz_all, *dx_all = bws + bw.dx_all, *dh_all = bws + bw.dh_all;
+    float *dy = bws + bw.dy;
     float *dx0 = bws + bw.dx0, *scr = bws + bw.scratch;
+    const long dz_bs = (long)((size_t)NL * 2 * CL), dx_bs = (long)((size_t)(NL + 1) * CL);
     const float rsNL = 1.0f / sqrtf((float)NL);
 
     // ---- head: output_projection, ReLU, skip_projection (model/modules.py:441-444) ------------
@@ -198,41 +227,56 @@ extern "C" int mg_denoiser_bwd(const mg_denoiser_dims *d, const float *packed, c
         MG_TRY(wgrad_launch(s, dy, ws + w.skip, nullptr, grads[4], scr, rsNL, 0, st));
     }
     if (grads[5]) MG_TRY(rowsum(dy, 0, B, C, L, grads[5], nullptr, 1.f, st));
-    {   // the last layer's x output is unused: dx_NL = 0
+    {   // the last layer's x output is unused: dx_NL = 0 (in dout's top half and in slot NL of dx_all)
         hipError_t e = hipMemset2DAsync(dout, 2 * CL * sizeof(float), 0, CL * sizeof(float), B, st);
+        if (e != hipSuccess) return (int)e;
+        e = hipMemset2DAsync(dx_all + (size_t)NL * CL, (size_t)dx_bs * sizeof(float), 0, CL * sizeof(float), B, st);
         if (e != hipSuccess) return (int)e;
     }
 
-    // ---- residual layers, top to bottom ------------------------------------------------------
+    // ---- residual layers, top to bottom: data gradients only (2 launches per layer) ------------
+    // dout = [dx_l / sqrt2 ; dskip]; slot l+1 of dx_all holds the dx that ENTERS layer l, slot l the one it produces
     for (int l = NL - 1; l >= 0; --l) {
         const float *bp = packed + o.blayers + (size_t)l * o.blayer_stride;
-        const float *h_l = ws + w.h + (size_t)l * w.act_stride;
-        const float *g_l = ws + w.g + (size_t)l * w.act_stride;
         const float *sig_l = ws + w.sig + (size_t)l * w.act_stride;
         const float *tnh_l = ws + w.tnh + (size_t)l * w.act_stride;
-        if (LG(l, 5)) {
-            WgradShape s{B, 2 * C, C, L, L, 1, 1, 0, 0, 0};
-            MG_TRY(wgrad_launch(s, dout, g_l, nullptr, LG(l, 5), scr, 1.f, 0, st));
-        }
-        if (LG(l, 6)) MG_TRY(rowsum(dout, 0, B, 2 * C, L, LG(l, 6), nullptr, 1.f, st));
+        float *dz_l = dz_all + (size_t)l * 2 * CL;
         {
             ConvShape s{B, 2 * C, L, L, 1, 1, 0, C, 0, 0};
-            EpiGateBwd::Params ep{dz, sig_l, tnh_l, C};
+            EpiGateBwd::Params ep{dz_l, sig_l, tnh_l, C, dz_bs};
             MG_TRY(conv_launch<EpiGateBwd>(s, dout, nullptr, bp + o.bl_woT, ep, st));
         }
-        if (LG(l, 0)) {
-            WgradShape s{B, 2 * C, C, L, L, 3, 1, 1, 0, 0};
-            MG_TRY(wgrad_launch(s, dz, h_l, nullptr, LG(l, 0), scr, 1.f, 0, st));
-        }
-        if (LG(l, 1)) MG_TRY(rowsum(dz, 0, B, 2 * C, L, LG(l, 1), nullptr, 1.f, st));
         {
-            ConvShape s{B, 2 * C, L, L, 3, 1, 1, C, 0, 0};
-            EpiDhBwd::Params ep{dh_all + (size_t)l * CL, (long)((size_t)NL * CL), dout, C};
-            MG_TRY(conv_launch<EpiDhBwd>(s, dz, nullptr, bp + o.bl_w3T, ep, st));
+            ConvShape s{B, 2 * C, L, L, 3, 1, 1, C, dz_bs, 0};
+            EpiDhBwd::Params ep{dh_all + (size_t)l * CL, (long)((size_t)NL * CL), dout, C, dx_all + (size_t)l * CL, dx_bs};
+            MG_TRY(conv_launch<EpiDhBwd>(s, dz_l, nullptr, bp + o.bl_w3T, ep, st));
         }
-        // d(Wd s)_l = sum_frames dx_l  (the step vector enters h and the residual, model/blocks.py:1166)
-        MG_TRY(rowsum(dout, (long)(2 * CL), B, C, L, nullptr, bws + bw.dd_all + (size_t)l * B * C, 1.41421356237309504880f,
-                      st));
+    }
+
+    // ---- weight / bias gradients of all residual layers, grouped over the layer axis ----------------------------
+    {
+        const float *h_all = ws + w.h, *g_all = ws + w.g;
+        const long act_gs = (long)w.act_stride;
+        if (LG(0, 0))   // k=3 conv: dW3_l = dz_l (*) h_l
+            MG_TRY(wgrad_grouped(NL, dz_all, dz_bs, (long)(2 * CL), h_all, (long)CL, act_gs, LG(0, 0), (long)2 * C * C * 3, scr,
+                                 B, 2 * C, C, L, 3, 1, st));
+        if (LG(0, 1)) MG_TRY(rowsum(dz_all, 0, B, NL * 2 * C, L, LG(0, 1), nullptr, 1.f, st));
+        if (LG(0, 5)) {   // output conv: rows < C see dx_l (slot l+1), rows >= C the layer-independent dskip
+            MG_TRY(wgrad_grouped(NL, dx_all + CL, dx_bs, (long)CL, g_all, (long)CL, act_gs, LG(0, 5), (long)2 * C * C, scr, B, C,
+                                 C, L, 1, 0, st));
+            MG_TRY(wgrad_grouped(NL, dout + CL, (long)(2 * CL), 0, g_all, (long)CL, act_gs, LG(0, 5) + (size_t)C * C,
+                                 (long)2 * C * C, scr, B, C, C, L, 1, 0, st));
+        }
+        if (LG(0, 6)) {
+            MG_TRY(rowsum(dx_all + CL, dx_bs, B, NL * C, L, bws + bw.btop, nullptr, 1.f, st));
+            MG_TRY(rowsum(dout + CL, (long)(2 * CL), B, C, L, bws + bw.bbot, nullptr, 1.f, st));
+            hipLaunchKernelGGL(bias_scatter_kernel, dim3(mg_cdiv(NL * 2 * C, 256)), dim3(256), 0, st, bws + bw.btop,
+                               bws + bw.bbot, LG(0, 6), NL, C);
+            MG_LAUNCH_CHECK();
+        }
+        // d(Wd s)_l = sqrt2 * sum_frames of the dx layer l produced (slot l): [B][NL*C] per-sample sums
+        // (the step vector enters h and the residual, model/blocks.py:1166)
+        MG_TRY(rowsum(dx_all, dx_bs, B, NL * C, L, nullptr, bws + bw.dd_all, 1.41421356237309504880f, st));
     }
 
     // ---- input projection + ReLU (model/modules.py:430-431) -----------------------------------
@@ -288,8 +332,8 @@ extern "C" int mg_denoiser_bwd(const mg_denoiser_dims *d, const float *packed, c
         return e == hipSuccess ? MG_OK : (int)e;
     };
     const float *dd_all = bws + bw.dd_all;
-    if (LG(0, 2)) MG_TRY(outer(dd_all, (long)B * C, C, ws + w.s, LG(0, 2), NL, C, C));
-    MG_TRY(linear_t(lay0 + o.l_wd, (long)o.layer_stride, dd_all, (long)B * C, C, bws + bw.ds, NL, C, C));
+    if (LG(0, 2)) MG_TRY(outer(dd_all, C, (long)NL * C, ws + w.s, LG(0, 2), NL, C, C));
+    MG_TRY(linear_t(lay0 + o.l_wd, (long)o.layer_stride, dd_all, C, (long)NL * C, bws + bw.ds, NL, C, C));
     if (d->multi_speaker) {
         const float *dhv = bws + bw.dhv_all;  // [B, NL*C]
         if (LG(0, 7)) MG_TRY(outer(dhv, C, (long)NL * C, spk, LG(0, 7), NL, C, H));

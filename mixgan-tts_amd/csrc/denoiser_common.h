@@ -151,7 +151,10 @@ static inline DenWs den_ws(const mg_denoiser_dims *d, int B, int L, int save)
 
 // ------------------------------------------------------------------------------------------ backward workspace
 struct DenBws {
-    size_t dout, dz, dh_all, dy, dx0, scratch, dd_all, dhv_all, ds, dm, da, total;
+    // dz_all [B][NL*2C][L] and dx_all [B][(NL+1)*C][L] keep every layer's gate-pre-activation gradient and residual
+    // gradient so that the weight / bias gradients of all layers are computed in a handful of grouped launches at
+    // the end (0.5 GB at B=8, L=1000 -- 0.2 % of HBM) instead of 5 small launches per layer.
+    size_t dout, dz_all, dx_all, dh_all, dy, dx0, scratch, dd_all, dhv_all, ds, dm, da, btop, bbot, total;
 };
 
 static inline DenBws den_bws(const mg_denoiser_dims *d, int B, int L)
@@ -166,7 +169,8 @@ static inline DenBws den_bws(const mg_denoiser_dims *d, int B, int L)
         return at;
     };
     w.dout = take(2 * act);
-    w.dz = take(2 * act);
+    w.dz_all = take(2 * NL * act);
+    w.dx_all = take((NL + 1) * act);
     w.dh_all = take(NL * act);
     w.dy = take(act);
     w.dx0 = take(act);
@@ -179,7 +183,15 @@ static inline DenBws den_bws(const mg_denoiser_dims *d, int B, int L)
         const size_t need = mg_conv1d_wgrad_scratch_floats(sh[0], sh[1], sh[2]);
         if (need > sc) sc = need;
     }
+    {   // the grouped gradients of the residual layers: k=3 conv [2C, C, 3] and the two row halves of the output conv
+        const size_t g3 = mg_conv1d_wgrad_grouped_scratch_floats(2 * c, c, 3, nl);
+        const size_t go = mg_conv1d_wgrad_grouped_scratch_floats(c, c, 1, nl);
+        if (g3 > sc) sc = g3;
+        if (go > sc) sc = go;
+    }
     w.scratch = take(sc);
+    w.btop = take((size_t)NL * C);
+    w.bbot = take(C);
     w.dd_all = take(NL * B * C);
     w.dhv_all = take(NL * B * C);
     w.ds = take(B * C);

@@ -23,10 +23,14 @@ struct WgradArgs {
     const float *dy;    // [B, Co, Ldy] (batch stride dy_bs, row stride Ldy)
     const float *x;     // [B, Ci, Lx]  (batch stride x_bs,  row stride Lx)
     const float *xvec;  // optional [B, Ci]
-    float *scratch;     // [nsplit][K][Co][Ci] partial sums
+    float *scratch;     // [nsplit][G][K][Co][Ci] partial sums
     long dy_bs, x_bs;
     int B, Co, Ci, Ldy, Lx, K, stride, pad;
     int chunks_per_b, nchunks, nsplit, ci_tiles;
+    // G independent gradients of the same shape in one launch (the 20 residual layers of the denoiser): group g
+    // reads dy + g*dy_gs and x + g*x_gs (a stride of 0 shares the operand); blockIdx.z = g*K + tap
+    int G;
+    long dy_gs, x_gs;
 };
 
 // VEC: 16-byte staging loads (needs stride 1, Ldy % 4 == 0, Lx % 4 == 0, 16-byte aligned bases, no xvec):
@@ -45,7 +49,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a)
     const int split = blockIdx.x;
     const int co0 = (blockIdx.y / a.ci_tiles) * 128;
     const int ci0 = (blockIdx.y % a.ci_tiles) * 128;
-    const int tap = blockIdx.z;
+    const int grp = blockIdx.z / a.K;
+    const int tap = blockIdx.z - grp * a.K;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -64,8 +69,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a)
     auto load_stage = [&](int chunk) {
         const int b = chunk / a.chunks_per_b;
         const int f0 = (chunk - b * a.chunks_per_b) * WG_FT;
-        const float *dyb = a.dy + (size_t)b * a.dy_bs;
-        const float *xb = a.x + (size_t)b * a.x_bs;
+        const float *dyb = a.dy + (size_t)grp * a.dy_gs + (size_t)b * a.dy_bs;
+        const float *xb = a.x + (size_t)grp * a.x_gs + (size_t)b * a.x_bs;
         if (VEC) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a)
     }
 
     // acc[i][j][r]: co = co0 + wm*64 + i*32 + 8*(r>>2) + 4*hh + (r&3),  ci = ci0 + wn*64 + j*32 + c32
-    float *dst = a.scratch + ((size_t)split * a.K + tap) * a.Co * a.Ci;
+    float *dst = a.scratch + (((size_t)split * a.G + grp) * a.K + tap) * a.Co * a.Ci;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -189,28 +194,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a)
         }
 }
 
-// scratch [nsplit][K][Co][Ci] -> dw [Co][Ci][K] (= or +=), scaled; splits summed in index order
+// scratch [nsplit][G][K][Co][Ci] -> dw[g] [Co][Ci][K] (= or +=), scaled; splits summed in index order
 __global__ void wgrad_finalize_kernel(const float *__restrict__ scratch, float *__restrict__ dw, int Co, int Ci, int K,
-                                      int nsplit, float alpha, int accumulate)
+                                      int G, long dw_gs, int nsplit, float alpha, int accumulate)
 {
-    const size_t n = (size_t)Co * Ci * K;
+    const size_t per = (size_t)Co * Ci * K, n = per * G;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        // thread <-> scratch element (k, co, ci): coalesced reads of every split; the [Co][Ci][K] write is strided by K
-        const size_t cc = i % ((size_t)Co * Ci);
-        const int k = (int)(i / ((size_t)Co * Ci));
+        // thread <-> scratch element (g, k, co, ci): coalesced reads of every split; the [Co][Ci][K] write is strided by K
+        const size_t g = i / per, r = i - g * per;
+        const size_t cc = r % ((size_t)Co * Ci);
+        const int k = (int)(r / ((size_t)Co * Ci));
         float v = 0.f;
         for (int s = 0; s < nsplit; ++s) v += scratch[(size_t)s * n + i];
         v *= alpha;
-        float *o = dw + cc * K + k;
+        float *o = dw + g * dw_gs + cc * K + k;
         *o = accumulate ? *o + v : v;
     }
 }
 
 // number of frame splits for a [Co, Ci, K] gradient: two workgroups per CU are resident (66.5 KB LDS each), keep
 // the grid within ONE round of 512 workgroups -- 560 workgroups take two rounds, i.e. twice the time of 504
-static inline int wgrad_nsplit(int Co, int Ci, int K)
+static inline int wgrad_nsplit(int Co, int Ci, int K, int G = 1)
 {
-    const int tiles = mg_cdiv(Co, 128) * mg_cdiv(Ci, 128) * K;
+    const int tiles = mg_cdiv(Co, 128) * mg_cdiv(Ci, 128) * K * G;
     // measured sweep (B=8, L=1000): 512 workgroups is the optimum for every shape with more than 8 tiles; the small
     // k=1 gradients (<= 8 tiles: 512x256, 256x256) are 10-25 % faster with 256 -- their finalize pass, which reads
     // nsplit copies of the output, is as long as the GEMM itself
@@ -218,21 +224,26 @@ static inline int wgrad_nsplit(int Co, int Ci, int K)
     const int n = target / tiles;
     return n < 1 ? 1 : n;
 }
-static inline size_t wgrad_scratch_floats(int Co, int Ci, int K)
+static inline size_t wgrad_scratch_floats(int Co, int Ci, int K, int G = 1)
 {
-    return (size_t)wgrad_nsplit(Co, Ci, K) * Co * Ci * K;
+    return (size_t)wgrad_nsplit(Co, Ci, K, G) * G * Co * Ci * K;
 }
 
 struct WgradShape {
     int B, Co, Ci, Ldy, Lx, K, stride, pad;
     long dy_bs, x_bs;  // 0 -> dense
+    int G = 1;         // groups (see WgradArgs)
+    long dy_gs = 0, x_gs = 0, dw_gs = 0;
 };
 
 static int wgrad_launch(const WgradShape &s, const float *dy, const float *x, const float *xvec, float *dw,
                         float *scratch, float alpha, int accumulate, hipStream_t st)
 {
-    if (s.B <= 0 || s.Co <= 0 || s.Ci <= 0 || s.Ldy <= 0 || s.Lx <= 0 || s.K <= 0) return MG_ERR_SHAPE;
+    if (s.B <= 0 || s.Co <= 0 || s.Ci <= 0 || s.Ldy <= 0 || s.Lx <= 0 || s.K <= 0 || s.G <= 0) return MG_ERR_SHAPE;
     WgradArgs a;
+    a.G = s.G;
+    a.dy_gs = s.dy_gs;
+    a.x_gs = s.x_gs;
     a.dy = dy;
     a.x = x;
     a.xvec = xvec;
@@ -250,19 +261,19 @@ static int wgrad_launch(const WgradShape &s, const float *dy, const float *x, co
     a.chunks_per_b = mg_cdiv(s.Ldy, WG_FT);
     a.nchunks = a.chunks_per_b * s.B;
     a.ci_tiles = mg_cdiv(s.Ci, 128);
-    int nsplit = wgrad_nsplit(s.Co, s.Ci, s.K);
+    int nsplit = wgrad_nsplit(s.Co, s.Ci, s.K, s.G);
     if (nsplit > a.nchunks) nsplit = a.nchunks;
     a.nsplit = nsplit;
-    const size_t n = (size_t)s.Co * s.Ci * s.K;
-    dim3 grid(nsplit, mg_cdiv(s.Co, 128) * a.ci_tiles, s.K);
+    const size_t n = (size_t)s.Co * s.Ci * s.K * s.G;
+    dim3 grid(nsplit, mg_cdiv(s.Co, 128) * a.ci_tiles, s.K * s.G);
     const bool vec = s.stride == 1 && !xvec && (s.Ldy % 4 == 0) && (s.Lx % 4 == 0) && (a.dy_bs % 4 == 0) &&
-                     (a.x_bs % 4 == 0) && ((((uintptr_t)dy | (uintptr_t)x) & 15) == 0) && s.Ldy >= 4 && s.Lx >= 4;
+                     (a.x_bs % 4 == 0) && (a.dy_gs % 4 == 0) && (a.x_gs % 4 == 0) && ((((uintptr_t)dy | (uintptr_t)x) & 15) == 0) && s.Ldy >= 4 && s.Lx >= 4;
     if (vec) hipLaunchKernelGGL(wgrad_mfma_kernel<true>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(wgrad_mfma_kernel<false>, grid, dim3(256), 0, st, a);
     MG_LAUNCH_CHECK();
     const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, st, scratch, dw, s.Co, s.Ci, s.K, nsplit, alpha,
-                       accumulate);
+    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, st, scratch, dw, s.Co, s.Ci, s.K, s.G,
+                       s.dw_gs ? s.dw_gs : (long)s.Co * s.Ci * s.K, nsplit, alpha, accumulate);
     MG_LAUNCH_CHECK();
     return MG_OK;
 }

@@ -155,13 +155,17 @@ class Denoiser(nn.Module):
         table = self._weight_table()
         new = lambda p: torch.empty_like(p)
         grads = [new(p) if p is not None else None for p in table[:8]]
+        # per-layer gradients are slices of layer-major tensors: mg_denoiser_bwd computes them for all layers at once
+        g_w3 = torch.empty(NL, 2 * C, C, 3, device=dev)
+        g_b3 = torch.empty(NL, 2 * C, device=dev)
+        g_wo = torch.empty(NL, 2 * C, C, 1, device=dev)
+        g_bo = torch.empty(NL, 2 * C, device=dev)
         g_wd = torch.empty(NL, C, C, device=dev)
         g_wc = torch.empty(NL, C, H, 1, device=dev)
         g_bc = torch.empty(NL, C, device=dev)
         g_wp = torch.empty(NL, C, H, device=dev) if self.multi_speaker else None
         for l, blk in enumerate(self.residual_layers):
-            grads += [new(blk.conv_layer.conv.weight), new(blk.conv_layer.conv.bias), g_wd[l], g_wc[l], g_bc[l],
-                      new(blk.output_projection.conv.weight), new(blk.output_projection.conv.bias),
+            grads += [g_w3[l], g_b3[l], g_wd[l], g_wc[l], g_bc[l], g_wo[l], g_bo[l],
                       g_wp[l] if self.multi_speaker else None, None]
         ptrs = (ctypes.c_void_p * len(grads))(*[None if g is None else g.data_ptr() for g in grads])
         d_x = torch.empty_like(x_t) if want_dx else None

@@ -125,3 +125,29 @@ def test_denoiser_backward_vs_oracle_autograd_ragged(mg, manifest, tmp_path):
     assert_close(cg.grad.cpu(), cr.grad, GT, "d_cond")
     for k, p in den.named_parameters():
         assert_close(p.grad.cpu(), W[k].grad, 1e-4, k)
+
+
+def test_grouped_wgrad_matches_per_group_calls(mg):
+    """mg_conv1d_wgrad_grouped: G gradients of one shape in one launch (shared or per-group operands, strided
+    slots inside wider tensors) == G separate mg_conv1d_wgrad calls."""
+    import ctypes
+    G, B, Co, Ci, K, L = 5, 3, 96, 40, 3, 204
+    gen = torch.Generator().manual_seed(12)
+    dy_all = torch.randn(B, G * Co, L, generator=gen).cuda()          # slots in the row dimension: [B][G*Co][L]
+    x_all = torch.randn(G, B, Ci, L, generator=gen).cuda()            # layer-major saves: [G][B][Ci][L]
+    lib = mg._lib.lib()
+    cp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    scratch = torch.empty(lib.mg_conv1d_wgrad_grouped_scratch_floats(Co, Ci, K, G), device="cuda")
+    dw = torch.empty(G, Co, Ci, K, device="cuda")
+    mg._lib.check(lib.mg_conv1d_wgrad_grouped(cp(dy_all), G * Co * L, Co * L, cp(x_all), Ci * L, B * Ci * L, cp(dw), 0,
+                                              cp(scratch), G, B, Co, Ci, L, L, K, 1, 1, 1.0, 0, None))
+    for g in range(G):
+        ref = mg.ops.conv1d_wgrad(dy_all[:, g * Co:(g + 1) * Co].contiguous(), x_all[g], K, 1, 1)
+        assert_close(dw[g].cpu(), ref.cpu(), 1e-6, "grouped wgrad group %d" % g)
+    # shared dy (group stride 0), accumulate into an existing gradient
+    dw2 = torch.ones(G, Co, Ci, K, device="cuda")
+    mg._lib.check(lib.mg_conv1d_wgrad_grouped(cp(dy_all), G * Co * L, 0, cp(x_all), Ci * L, B * Ci * L, cp(dw2), 0,
+                                              cp(scratch), G, B, Co, Ci, L, L, K, 1, 1, 0.5, 1, None))
+    for g in range(G):
+        ref = 1.0 + 0.5 * mg.ops.conv1d_wgrad(dy_all[:, :Co].contiguous(), x_all[g], K, 1, 1)
+        assert_close(dw2[g].cpu(), ref.cpu(), 1e-6, "grouped wgrad shared dy, group %d" % g)
