@@ -142,3 +142,45 @@ def test_trainer_step_runs_and_leaks_d_grads(mg, manifest, tmp_path):
     assert all(torch.isfinite(v).all() for v in out2.values())
     trainer.end_epoch()
     assert abs(trainer.optG.param_groups[0]["lr"] - 1e-4 * 0.999) < 1e-12
+
+
+def test_batch_shard_gradients_average_to_the_full_batch(mg, manifest, tmp_path):
+    """What the multi-GPU design rests on: with equal shard sizes and equal frame counts, the
+    mean over ranks of the per-shard generator gradients equals the single-process gradient of the whole batch --
+    checked on the real kernels with the t / noise draws of each sample pinned (two 'ranks' = two halves of B=4)."""
+    e = golden("elementwise")
+    stats = write_stats(tmp_path, e["spec_min"], e["spec_max"])
+    args, pre, mc, tr = hot_path_configs("naive", 4, stats_dir=stats)
+    G = mg.GaussianDiffusion(args, pre, mc, tr)
+    load_seeded(G, manifest, "diffusion_naive_ms0", 61)
+    with torch.no_grad():   # the fixture recipe leaves output_projection at its zero init: make the path live
+        G.denoise_fn.output_projection.conv.weight.normal_(0, 0.05, generator=torch.Generator().manual_seed(3))
+    G = G.cuda()
+    B, L = 4, 96
+    gen = torch.Generator().manual_seed(21)
+    mel = torch.rand(B, L, 80, generator=gen) * 13.5 - 11.5
+    cond = torch.randn(B, L, 256, generator=gen)
+    pad = torch.zeros(B, L, dtype=torch.bool)
+    t = torch.tensor([3, 0, 2, 1])
+    noises = [torch.randn(B, 1, 80, L, generator=gen) for _ in range(3)]
+
+    def grads(lo, hi):
+        G.zero_grad(set_to_none=True)
+        G.t_fn = Tape([t[lo:hi].numpy()])
+        G.noise_fn = Tape([n[lo:hi].numpy() for n in noises])
+        c = cond[lo:hi].cuda().requires_grad_()
+        x0, *_ = G(mel[lo:hi].cuda(), c, None, pad[lo:hi].cuda())
+        loss = mg.losses.get_mel_loss(G.denorm_spec(x0), mel[lo:hi].cuda(), pad[lo:hi].cuda())
+        loss.backward()
+        return {k: p.grad.detach().clone() for k, p in G.named_parameters() if p.grad is not None}, c.grad.clone()
+
+    full, dc_full = grads(0, B)
+    h0, dc0 = grads(0, B // 2)
+    h1, dc1 = grads(B // 2, B)
+    assert len(full) > 100
+    for k, g in full.items():
+        avg = 0.5 * (h0[k] + h1[k])
+        scale = g.abs().max().item() + 1e-12
+        assert (avg - g).abs().max().item() <= 2e-4 * scale + 1e-9, k
+    # the conditioner gradient of a sample only depends on its own shard (scaled by the shard's share of the mean)
+    assert_close(torch.cat([dc0, dc1]).cpu() * 0.5, dc_full.cpu(), 2e-4, "d_cond across shards")
