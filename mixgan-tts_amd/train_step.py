@@ -40,6 +40,17 @@ class HotPathTrainer:
         opt.step()
         opt.zero_grad()                               # after step, as train.py:84-85
 
+    def _d_fake_and_real(self, x_ts, x_fake, x_real, spk, t):
+        """D(x_ts, x_fake, s, t) and D(x_ts, x_real, s, t) (train.py:139-140,156-157) as ONE pass over a batch of 2B:
+        the discriminator has no batch-coupled op, so the feature maps are the same as from two calls, and every
+        conv of its 1/4-rate tail sees twice the frames per launch (at B=8 those launches fill a quarter of the
+        GPU).  Returns (fake_cond, fake_uncond, real_cond, real_uncond) lists of feature maps."""
+        B = x_ts.shape[0]
+        both = lambda a, b: None if a is None else torch.cat([a, b], 0)  # noqa: E731
+        cond_maps, uncond_maps = self.D(both(x_ts, x_ts), both(x_fake, x_real), both(spk, spk), both(t, t))
+        halves = lambda maps, k: [m[k * B:(k + 1) * B] for m in maps]  # noqa: E731
+        return halves(cond_maps, 0), halves(uncond_maps, 0), halves(cond_maps, 1), halves(uncond_maps, 1)
+
     def step(self, mel, cond, spk, mel_pad_mask, coarse_mel=None):
         """One D phase + one G phase on a batch.  mel [B,L,M]; cond [B,L,H]; mel_pad_mask True = pad."""
         G, D = self.G, self.D
@@ -51,16 +62,14 @@ class HotPathTrainer:
             x0, x_ts, x_prevs, x_prev_preds, t = G(mel, cond, spk, mel_pad_mask, coarse_mel)
         x_ts_d, x_prevs_d, x_pp_d = x_ts.detach(), x_prevs.detach(), x_prev_preds.detach()
         spk_d = spk.detach() if spk is not None else None
-        f_c, f_u = D(x_ts_d, x_pp_d, spk_d, t)
-        r_c, r_u = D(x_ts_d, x_prevs_d, spk_d, t)
+        f_c, f_u, r_c, r_u = self._d_fake_and_real(x_ts_d, x_pp_d, x_prevs_d, spk_d, t)
         d_real, d_fake = self.d_loss_fn(r_c[-1], r_u[-1], f_c[-1], f_u[-1])
         d_loss = d_real + d_fake
         d_loss.backward()
         self._update(list(D.parameters()), self.bucketD, self.optD)
         # ---------------- G phase (train.py:153-184)
         x0, x_ts, x_prevs, x_prev_preds, t = G(mel, cond, spk, mel_pad_mask, coarse_mel)
-        f_c, f_u = D(x_ts, x_prev_preds, spk, t)
-        r_c, r_u = D(x_ts, x_prevs, spk, t)
+        f_c, f_u, r_c, r_u = self._d_fake_and_real(x_ts, x_prev_preds, x_prevs, spk, t)
         adv = self.g_loss_fn(f_c[-1], f_u[-1])
         target = coarse_mel.detach() if G.model == "shallow" else mel
         mel_loss = losses.get_mel_loss(G.denorm_spec(x0), target, mel_pad_mask)
