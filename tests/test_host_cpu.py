@@ -33,6 +33,21 @@ def test_error_strings_and_arg_checks():
     assert L.mg_conv_packed_floats(512, 256, 6, 0) == 0          # unsupported kernel size
     # null pointers are rejected before any launch (no GPU needed)
     assert L.mg_conv1d_fwd(None, None, None, None, None, None, 1, 8, 8, 8, 8, 1, 1, 0, 0, 1.0, 0, None) == -1
+    # the entry points added for the vocoder / aux-training / grouped-gradient rows: sizes and argument checks
+    assert L.mg_conv_transpose_packed_floats(512, 256, 8) == (256 * 8 // 32) * (512 * 3 // 8) * 256
+    assert L.mg_conv_transpose_packed_floats(512, 256, 3) == 0                       # stride must be 2, 4 or 8
+    assert L.mg_conv_transpose_pack(None, None, 512, 256, 8, None) == -1
+    assert L.mg_conv_transpose1d_fwd(None, None, None, None, 1, 8, 8, 8, 2, 1.0, 1.0, None) == -1
+    assert L.mg_bgemm(None, None, None, 4, 4, 4, 1, 1, 1, 4, 0, 0, 4, 1, 0, 0, 4, 0, 0, 1.0, 0, None) == -1
+    assert L.mg_softmax_rows_fwd(None, None, 1, 1, 4, 1.0, None) == -1
+    assert L.mg_layernorm_cm_bwd(None, None, None, None, None, 1.0, None, None, None, None, 1, 256, 4, 1e-5, None) == -1
+    assert L.mg_bn_stats(None, None, None, 1, 4, 4, None) == -1
+    assert L.mg_attention_fwd_f16(None, None, None, 1, 4, 2, 128, 1.0, None) == -1
+    assert L.mg_diffuse_trace_bwd(None, None, None, None, None, None, None, 4, 1, 4, 80, None) == -1
+    assert L.mg_conv1d_wgrad_grouped_scratch_floats(512, 256, 3, 20) == 20 * 512 * 256 * 3     # 480 tiles: no frame split
+    assert L.mg_conv1d_wgrad_grouped_scratch_floats(256, 256, 1, 20) == 6 * 20 * 256 * 256     # 80 tiles -> 6 splits
+    assert L.mg_conv1d_wgrad_scratch_floats(512, 256, 1) == 32 * 512 * 256                    # <= 8 tiles: 256-workgroup target
+    assert L.mg_conv1d_wgrad_grouped(None, 0, 0, None, 0, 0, None, 0, None, 2, 1, 8, 8, 8, 8, 1, 1, 0, 1.0, 0, None) == -1
 
 
 def test_schedule_matches_reference_bits():
