@@ -13,6 +13,7 @@ __device__ __forceinline__ float denorm1(float x, float mn, float mx) { return (
 // ---------------------------------------------------------------------------------------------
 // mel [B,L,M] -> x_t [B,M,L]
 // ---------------------------------------------------------------------------------------------
+template <bool VEC>
 __global__ __launch_bounds__(256) void diffuse_kernel(const float *__restrict__ mel, const int64_t *__restrict__ t,
                                                       const float *__restrict__ noise,
                                                       const uint8_t *__restrict__ keep,
@@ -27,10 +28,18 @@ __global__ __launch_bounds__(256) void diffuse_kernel(const float *__restrict__ 
     const int l0 = blockIdx.x * TL;
     const int nl = min(TL, L - l0);
     const int P = M + 1;
+    constexpr int W = VEC ? 4 : 1;
     const float *src = mel + ((size_t)b * L + l0) * M;
-    for (int idx = threadIdx.x; idx < nl * M; idx += 256) {
-        const int l = idx / M, m = idx - l * M;
-        tile[l * P + m] = norm1(src[idx], spec_min[m], spec_max[m]);
+    for (int idx = threadIdx.x; idx < nl * M / W; idx += 256) {
+        const int e = idx * W;
+        const int l = e / M, m = e - l * M;
+        if (VEC) {
+            const f32x4 q = *reinterpret_cast<const f32x4 *>(src + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile[l * P + m + j] = norm1(q[j], spec_min[m + j], spec_max[m + j]);
+        } else {
+            tile[l * P + m] = norm1(src[e], spec_min[m], spec_max[m]);
+        }
     }
     __syncthreads();
     long tb = t[b];
@@ -38,14 +47,30 @@ __global__ __launch_bounds__(256) void diffuse_kernel(const float *__restrict__ 
     if (tb < 0) tb = 0;
     if (tb >= T) tb = T - 1;
     const float ca = sqrt_ac[tb], cb = sqrt_1mac[tb];
-    for (int idx = threadIdx.x; idx < M * TL; idx += 256) {
-        const int m = idx / TL, l = idx - m * TL;
+    for (int idx = threadIdx.x; idx < M * TL / W; idx += 256) {
+        const int m = idx / (TL / W), l = (idx - m * (TL / W)) * W;
         if (l >= nl) continue;
         const size_t o = ((size_t)b * M + m) * L + l0 + l;
-        const float x0 = tile[l * P + m];
-        float v = clean ? x0 : ca * x0 + cb * noise[o];
-        if (keep) v *= (float)keep[(size_t)b * L + l0 + l];
-        out[o] = v;
+        float nz[W], v[W];
+        if (VEC) {
+            const f32x4 q = *reinterpret_cast<const f32x4 *>(noise + o);
+#pragma unroll
+            for (int j = 0; j < W; ++j) nz[j] = q[j];
+        } else {
+            nz[0] = clean ? 0.f : noise[o];
+        }
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const float x0 = tile[(l + j) * P + m];
+            v[j] = clean ? x0 : ca * x0 + cb * nz[j];
+            if (keep) v[j] *= (float)keep[(size_t)b * L + l0 + l + j];
+        }
+        if (VEC) {
+            f32x4 r = {v[0], v[W > 1 ? 1 : 0], v[W > 2 ? 2 : 0], v[W > 3 ? 3 : 0]};
+            *reinterpret_cast<f32x4 *>(out + o) = r;
+        } else {
+            out[o] = v[0];
+        }
     }
 }
 
@@ -56,8 +81,13 @@ extern "C" int mg_diffuse_fwd(const float *mel, const int64_t *t, const float *n
     if (!mel || !t || !noise || !spec_min || !spec_max || !sqrt_ac || !sqrt_1mac || !out) return MG_ERR_ARG;
     if (B <= 0 || L <= 0 || M <= 0 || M > 1024 || T <= 0) return MG_ERR_SHAPE;
     dim3 grid(mg_cdiv(L, TL), B);
-    hipLaunchKernelGGL(diffuse_kernel, grid, dim3(256), (size_t)TL * (M + 1) * sizeof(float), (hipStream_t)stream, mel,
-                       t, noise, keep, spec_min, spec_max, sqrt_ac, sqrt_1mac, out, L, M, T);
+    const bool vec = M % 4 == 0 && L % 4 == 0 && ((((uintptr_t)mel | (uintptr_t)noise | (uintptr_t)out) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(diffuse_kernel<true>, grid, dim3(256), (size_t)TL * (M + 1) * sizeof(float), (hipStream_t)stream,
+                           mel, t, noise, keep, spec_min, spec_max, sqrt_ac, sqrt_1mac, out, L, M, T);
+    else
+        hipLaunchKernelGGL(diffuse_kernel<false>, grid, dim3(256), (size_t)TL * (M + 1) * sizeof(float), (hipStream_t)stream,
+                           mel, t, noise, keep, spec_min, spec_max, sqrt_ac, sqrt_1mac, out, L, M, T);
     MG_LAUNCH_CHECK();
     return MG_OK;
 }
@@ -152,6 +182,9 @@ extern "C" int mg_posterior_sample_fwd(const float *x0, const float *x_t, const 
 // ---------------------------------------------------------------------------------------------
 // [B,M,L] <-> [B,L,M] with optional norm/denorm and keep mask
 // ---------------------------------------------------------------------------------------------
+// VEC: 16-byte global accesses on both sides (M % 4 == 0, L % 4 == 0, 16-byte aligned bases and batch stride); the LDS
+// tile keeps its odd pitch, so a vector is 4 scalar LDS accesses.  Same arithmetic as the scalar path.
+template <bool VEC, int TLV>
 __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, float *__restrict__ out,
                                                         const float *__restrict__ spec_min,
                                                         const float *__restrict__ spec_max,
@@ -159,41 +192,82 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
                                                         int M, long bml_bs)
 {
     // bml_bs: batch stride (floats) of the [B,M,L] side, so it may be a channel slice of a wider tensor
-    extern __shared__ float tile[];  // [TL][M+1]
+    extern __shared__ float tile[];  // [TLV][M+1]
     const int b = blockIdx.y;
-    const int l0 = blockIdx.x * TL;
-    const int nl = min(TL, L - l0);
+    const int l0 = blockIdx.x * TLV;
+    const int nl = min(TLV, L - l0);
     const int P = M + 1;
+    constexpr int W = VEC ? 4 : 1;
     if (to_blm) {
         // read [M][nl] rows of the BML tensor
-        for (int idx = threadIdx.x; idx < M * TL; idx += 256) {
-            const int m = idx / TL, l = idx - m * TL;
-            if (l < nl) tile[l * P + m] = in[(size_t)b * bml_bs + (size_t)m * L + l0 + l];
+        for (int idx = threadIdx.x; idx < M * TLV / W; idx += 256) {
+            const int m = idx / (TLV / W), l = (idx - m * (TLV / W)) * W;
+            if (l >= nl) continue;
+            const float *p = in + (size_t)b * bml_bs + (size_t)m * L + l0 + l;
+            if (VEC) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(p);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tile[(l + j) * P + m] = v[j];
+            } else {
+                tile[l * P + m] = *p;
+            }
         }
         __syncthreads();
         float *dst = out + ((size_t)b * L + l0) * M;
-        for (int idx = threadIdx.x; idx < nl * M; idx += 256) {
-            const int l = idx / M, m = idx - l * M;
-            float v = tile[l * P + m];
-            if (mode == 2) v = denorm1(v, spec_min[m], spec_max[m]);
-            if (keep) v *= (float)keep[(size_t)b * L + l0 + l];
-            dst[idx] = v;
+        for (int idx = threadIdx.x; idx < nl * M / W; idx += 256) {
+            const int e = idx * W;
+            const int l = e / M, m = e - l * M;
+            const float kp = keep ? (float)keep[(size_t)b * L + l0 + l] : 1.f;
+            float v[W];
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                v[j] = tile[l * P + m + j];
+                if (mode == 2) v[j] = denorm1(v[j], spec_min[m + j], spec_max[m + j]);
+                if (keep) v[j] *= kp;
+            }
+            if (VEC) {
+                f32x4 o = {v[0], v[W > 1 ? 1 : 0], v[W > 2 ? 2 : 0], v[W > 3 ? 3 : 0]};
+                *reinterpret_cast<f32x4 *>(dst + e) = o;
+            } else {
+                dst[e] = v[0];
+            }
         }
     } else {
         const float *src = in + ((size_t)b * L + l0) * M;
-        for (int idx = threadIdx.x; idx < nl * M; idx += 256) {
-            const int l = idx / M, m = idx - l * M;
-            float v = src[idx];
-            if (mode == 1) v = norm1(v, spec_min[m], spec_max[m]);
-            tile[l * P + m] = v;
+        for (int idx = threadIdx.x; idx < nl * M / W; idx += 256) {
+            const int e = idx * W;
+            const int l = e / M, m = e - l * M;
+            float v[W];
+            if (VEC) {
+                const f32x4 q = *reinterpret_cast<const f32x4 *>(src + e);
+#pragma unroll
+                for (int j = 0; j < W; ++j) v[j] = q[j];
+            } else {
+                v[0] = src[e];
+            }
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                if (mode == 1) v[j] = norm1(v[j], spec_min[m + j], spec_max[m + j]);
+                tile[l * P + m + j] = v[j];
+            }
         }
         __syncthreads();
-        for (int idx = threadIdx.x; idx < M * TL; idx += 256) {
-            const int m = idx / TL, l = idx - m * TL;
+        for (int idx = threadIdx.x; idx < M * TLV / W; idx += 256) {
+            const int m = idx / (TLV / W), l = (idx - m * (TLV / W)) * W;
             if (l >= nl) continue;
-            float v = tile[l * P + m];
-            if (keep) v *= (float)keep[(size_t)b * L + l0 + l];
-            out[(size_t)b * bml_bs + (size_t)m * L + l0 + l] = v;
+            float v[W];
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                v[j] = tile[(l + j) * P + m];
+                if (keep) v[j] *= (float)keep[(size_t)b * L + l0 + l + j];
+            }
+            float *p = out + (size_t)b * bml_bs + (size_t)m * L + l0 + l;
+            if (VEC) {
+                f32x4 o = {v[0], v[W > 1 ? 1 : 0], v[W > 2 ? 2 : 0], v[W > 3 ? 3 : 0]};
+                *reinterpret_cast<f32x4 *>(p) = o;
+            } else {
+                *p = v[0];
+            }
         }
     }
 }
@@ -216,8 +290,17 @@ extern "C" int mg_transpose_bml_strided(const float *in, float *out, const float
     if (mode < 0 || mode > 2 || (mode != 0 && (!spec_min || !spec_max))) return MG_ERR_ARG;
     if (B <= 0 || L <= 0 || M <= 0 || M > 1024) return MG_ERR_SHAPE;
     dim3 grid(mg_cdiv(L, TL), B);
-    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), (size_t)TL * (M + 1) * sizeof(float), (hipStream_t)stream, in,
-                       out, spec_min, spec_max, keep, to_blm, mode, L, M, bml_bs ? bml_bs : (long)M * L);
+    const long bs = bml_bs ? bml_bs : (long)M * L;
+    const bool vec = M % 4 == 0 && L % 4 == 0 && bs % 4 == 0 && ((((uintptr_t)in | (uintptr_t)out) & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    // measured (B=128, L=4000, M=80): [B,L,M] -> [B,M,L] goes from 4.1 to 5.6 TB/s with 16-byte accesses; the opposite
+    // direction (strided 256-byte row reads) is slightly SLOWER vectorised (2.3 vs 2.6 TB/s) and does not improve with
+    // 128-frame tiles either, so it keeps the scalar path
+    const size_t lds = (size_t)TL * (M + 1) * sizeof(float);
+    if (vec && !to_blm)
+        hipLaunchKernelGGL((transpose_kernel<true, TL>), grid, dim3(256), lds, st, in, out, spec_min, spec_max, keep, to_blm, mode, L, M, bs);
+    else
+        hipLaunchKernelGGL((transpose_kernel<false, TL>), grid, dim3(256), lds, st, in, out, spec_min, spec_max, keep, to_blm, mode, L, M, bs);
     MG_LAUNCH_CHECK();
     return MG_OK;
 }

@@ -373,8 +373,38 @@ def e2e_bench():
                           "audio_seconds_per_s": round(audio / t, 1)}), flush=True)
 
 
+def elementwise_bench():
+    """Rows a4-a6 (norm/denorm, diffuse_fn / q_sample, q_posterior_sample) are HBM-bound: GB/s against the 8 TB/s
+    spec at the bench size (B=16, L=1000: 20-26 MB per launch, launch-latency-limited) and at a size that fills the
+    memory system (B=128, L=4000: the global batch of configs[4])."""
+    dev = torch.device("cuda", 0)
+    d = tempfile.mkdtemp()
+    stats = write_stats(d, [-11.5] * 80, [2.0] * 80)
+    gd = mg.GaussianDiffusion(*hot_path_configs("naive", 4, stats_dir=stats)).to(dev)
+    buf = gd._buf()
+    for B, L in ((16, 1000), (128, 4000)):
+        M = 80
+        mel = torch.rand(B, L, M, device=dev) * 13.5 - 11.5
+        x = torch.randn(B, M, L, device=dev)
+        x2 = torch.randn(B, M, L, device=dev)
+        nz = torch.randn(B, M, L, device=dev)
+        t = torch.randint(0, 4, (B,), device=dev)
+        out = torch.empty_like(x)
+        res = {"config": "elementwise kernels B=%d L=%d" % (B, L)}
+        n = B * L * M * 4
+        for name, fn, nbytes in (
+                ("diffuse (mel + noise -> x_t)", lambda: mg.ops.diffuse(mel, t, nz, None, buf), 3 * n),
+                ("posterior (x0, x_t, noise -> x_t-1)", lambda: mg.ops.posterior_sample(x, x2, t, nz, None, buf, out=out), 4 * n),
+                ("transpose + denorm ([B,M,L] -> [B,L,M])", lambda: mg.ops.transpose_bml(x, True, 2, gd.spec_min, gd.spec_max), 2 * n)):
+            tt = timeit(fn, 3, 30)
+            res[name] = {"us": round(tt * 1e6, 1), "GBps": round(nbytes / tt / 1e9), "frac_of_8TBps": round(nbytes / tt / 8e12, 3)}
+        print(json.dumps(res), flush=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "e2e":
+    if len(sys.argv) > 1 and sys.argv[1] == "elementwise":
+        elementwise_bench()
+    elif len(sys.argv) > 1 and sys.argv[1] == "e2e":
         e2e_bench()
     elif len(sys.argv) > 1 and sys.argv[1] == "attention":
         attention_bench()
