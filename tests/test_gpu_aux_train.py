@@ -282,3 +282,55 @@ def test_aux_trainer_step_vs_oracle(mg, manifest, tmp_path):
         # first Adam step moves every element by ~lr (sign of the gradient)
         step = (named[k].detach() - b).abs().max().item()
         assert step <= lr * 1.001 + 1e-7 * max(1.0, b.abs().max().item())   # + fp32 rounding of the weight
+
+
+class _StubEncoder(torch.nn.Module):
+    """Stands in for the out-of-scope LinguisticEncoder: a trainable conditioner (so gradients must reach it)."""
+
+    def __init__(self, cond):
+        super().__init__()
+        self.cond = torch.nn.Parameter(cond)
+
+    def forward(self, texts, src_lens, word_boundaries, src_masks, src_w_lens, src_w_masks, mel_masks, max_mel_len,
+                attn_priors, p_targets, e_targets, d_targets, p_control, d_control):
+        return self.cond, None, None, None, None, mel_masks.sum(1), mel_masks, None, None
+
+
+def test_mixgantts_forward_aux_train_mode(mg, tmp_path):
+    """`MixGANTTS.forward` with args.model == "aux" in train mode (model/mixgantts.py:136-146): slot 0 is the
+    diffuse_trace list (T+1 normalised mels), slot 15 / the third return value the PostNet-refined coarse mel, and the
+    whole chain is differentiable down to the linguistic encoder's output."""
+    from helpers import write_stats
+    e = golden("elementwise")
+    stats = write_stats(tmp_path, e["spec_min"], e["spec_max"])
+    args, pre, mc, tr = hot_path_configs("aux", 4, stats_dir=stats, max_seq_len=1000)
+    B, L = 2, 40
+    gen = torch.Generator().manual_seed(4)
+    enc = _StubEncoder(torch.randn(B, L, 256, generator=gen))
+    net = mg.MixGANTTS(args, pre, mc, tr, linguistic_encoder=enc).cuda().train()
+    mels = (torch.rand(B, L, 80, generator=gen) * 8 - 9).cuda()
+    mel_lens = torch.tensor([40, 27]).cuda()
+    z = torch.zeros(B, 5, dtype=torch.long).cuda()
+    out, p_t, coarse = net(None, z, torch.tensor([5, 5]).cuda(), 5, None, torch.tensor([3, 3]).cuda(), 3,
+                           mels=mels, mel_lens=mel_lens, max_mel_len=L)
+    assert len(out) == 16 and isinstance(out[0], list) and len(out[0]) == 5      # T + 1 trace entries
+    assert out[1] == (None, None, None) and out[3] is None
+    assert out[15] is coarse and tuple(coarse.shape) == (B, L, 80) and coarse.requires_grad
+    pad = torch.arange(L)[None, :].cuda() >= mel_lens[:, None]
+    assert torch.equal(out[9], pad)
+    for tr_ in out[0]:
+        assert tuple(tr_.shape) == (B, L, 80) and float(tr_.detach()[1, 27:].abs().max()) == 0.0   # padded frames masked
+    assert float(out[0][0].detach().abs().max()) <= 1.0                                              # clamped normalised mel
+    loss = mg.losses._L1Fn.apply(coarse, mels)
+    for t_ in out[0]:
+        loss = loss + mg.losses.get_mel_loss(net.diffusion.denorm_spec(t_), mels, pad)
+    loss.backward()
+    assert enc.cond.grad is not None and torch.isfinite(enc.cond.grad).all() and float(enc.cond.grad.abs().sum()) > 0
+    assert all(p.grad is not None for n_, p in net.named_parameters()
+               if n_.split(".")[0] in ("decoder", "mel_linear", "postnet") and p.requires_grad)
+    # eval mode + no_grad keeps the inference behaviour (no autograd graph, running BatchNorm statistics)
+    net.eval()
+    with torch.no_grad():
+        out_e, _, coarse_e = net(None, z, torch.tensor([5, 5]).cuda(), 5, None, torch.tensor([3, 3]).cuda(), 3,
+                                 mels=mels, mel_lens=mel_lens, max_mel_len=L)
+    assert not coarse_e.requires_grad and len(out_e[0]) == 5
