@@ -19,5 +19,6 @@ from . import lingops, vocoder, data  # noqa: F401
 from .optimizer import ScheduledOptim  # noqa: F401
 from .mixgantts import MixGANTTS, get_mask_from_lengths  # noqa: F401
 from .transformer import Decoder, FFTBlock, PostNet, MultiHeadAttention, PositionwiseFeedForward  # noqa: F401
+from .model_io import get_model, save_checkpoint, get_param_num  # noqa: F401
 
 __version__ = "0.1.0"

@@ -124,3 +124,48 @@ def test_oracle_is_only_used_as_a_checker():
         for fn in files:
             if fn.endswith(".py"):
                 assert "/root/reference" not in open(os.path.join(dirpath, fn)).read(), fn
+
+
+def test_get_model_and_checkpoint_round_trip(tmp_path):
+    """utils/model.py:12-53 + train.py:252-267: the 8-tuple of the training entry, the checkpoint keys, a strict
+    restore of G / D / optimizer / scheduler state, eval-mode return, and the aux -> shallow optimizer restart.
+    Construction and state handling only -- no kernel is launched, so it runs without a GPU."""
+    import types
+    e = golden("elementwise")
+    stats = write_stats(tmp_path, e["spec_min"], e["spec_max"])
+    args, pre, mc, tr = hot_path_configs("shallow", 4, stats_dir=stats)
+    tr = dict(tr)
+    tr["path"] = {"ckpt_path": str(tmp_path / "ckpt")}
+    tr["step"] = {"total_step_aux": 7}
+    tr["optimizer_fs2"] = {"betas": [0.9, 0.98], "eps": 1e-9, "weight_decay": 0.0, "warm_up_step": 4000,
+                           "anneal_steps": [300000], "anneal_rate": 0.3}
+    configs = (pre, mc, tr)
+    a0 = types.SimpleNamespace(model="shallow", restore_step=0)
+    model, D, optG_fs2, optG, optD, sdlG, sdlD, epoch = mg.get_model(a0, configs, "cpu", train=True)
+    assert epoch == 1 and model.training and D.training and isinstance(optG_fs2, mg.ScheduledOptim)
+    assert mg.get_param_num(model) == sum(p.numel() for p in model.parameters()) > 20_000_000
+    # give the optimizers some state, then save as train.py does
+    for p in list(model.parameters())[:3] + list(D.parameters())[:3]:
+        p.grad = torch.ones_like(p)
+    optG.step(); optD.step(); optG_fs2.step(); sdlG.step(); sdlD.step()
+    path = mg.save_checkpoint(tr, 3, 5, model, D, optG_fs2, optG, optD, sdlG, sdlD)
+    ck = torch.load(path, weights_only=True)
+    assert tuple(ck.keys()) == ("epoch", "G", "D", "optG_fs2", "optG", "optD", "sdlG", "sdlD")
+    a3 = types.SimpleNamespace(model="shallow", restore_step=3)
+    m2, D2, f2, g2, d2, sg2, sd2, ep2 = mg.get_model(a3, configs, "cpu", train=True)
+    assert ep2 == 5
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k]), k
+    for k, v in D.state_dict().items():
+        assert torch.equal(v, D2.state_dict()[k]), k
+    assert g2.state_dict()["state"].keys() == optG.state_dict()["state"].keys() and len(g2.state_dict()["state"]) == 3
+    assert sg2.state_dict()["last_epoch"] == 1 and f2.current_step == 3
+    assert f2._optimizer.state_dict()["state"].keys() == optG_fs2._optimizer.state_dict()["state"].keys()
+    # eval entry (synthesize.py:245)
+    m3 = mg.get_model(a3, configs, "cpu", train=False)
+    assert not m3.training and torch.equal(m3.state_dict()["mel_linear.weight"], model.state_dict()["mel_linear.weight"])
+    # restore_step == total_step_aux: weights restored, optimizers start fresh (utils/model.py:41)
+    mg.save_checkpoint(tr, 7, 9, model, D, optG_fs2, optG, optD, sdlG, sdlD)
+    a7 = types.SimpleNamespace(model="shallow", restore_step=7)
+    _, _, f7, g7, *_ = mg.get_model(a7, configs, "cpu", train=True)
+    assert len(g7.state_dict()["state"]) == 0 and f7.current_step == 7
