@@ -249,6 +249,23 @@ int mg_linear_small_fwd(const float *x, const float *W, float *out, int B, int N
 int mg_linear_small_bwd(const float *g, const float *x, const float *W, float *dx, float *dW, int B,
                         int N, int K, void *stream);
 
+/* Stand-alone ResidualBlock.forward (model/blocks.py:1157-1176) on one layer's packs (mg_conv_pack: conditioner 1x1
+ * MG_PACK_PLAIN, k=3 conv MG_PACK_GATE, output 1x1 MG_PACK_PLAIN), the same fused kernel mg_denoiser_fwd launches per
+ * layer.  hvec [B,C] = Wd s (+ Wp spk) enters h, dvec [B,C] = Wd s the residual.  x_out [B,C,L] (must differ from x)
+ * and skip [B,C,L] are written.  h/g/sig/tnh_save [B,C,L]: all four (training) or all NULL.  C = H = 256. */
+int mg_resblock_fwd(const float *x, const float *cond, const float *wc_packed, const float *w3_packed,
+                    const float *wo_packed, const float *bc, const float *b3, const float *bo, const float *hvec,
+                    const float *dvec, float *x_out, float *skip, float *h_save, float *g_save, float *sig_save,
+                    float *tnh_save, int B, int C, int H, int L, void *stream);
+/* Derivative of the GLU gate g = sigmoid(z[:C]) * tanh(z[C:]) (model/blocks.py:1170-1171) through the saved
+ * sigmoid / tanh values: dg, sig, tnh [B,C,L] -> dz [B,2C,L]. */
+int mg_gate_bwd(const float *dg, const float *sig, const float *tnh, float *dz, int B, int C, int L, void *stream);
+/* Mish.forward (model/blocks.py:894-896): y = x tanh(softplus(x)), and its derivative gx = gy * mish'(x). */
+int mg_mish_fwd(const float *x, float *y, size_t n, void *stream);
+int mg_mish_bwd(const float *gy, const float *x, float *gx, size_t n, void *stream);
+/* DiffusionEmbedding.forward (model/blocks.py:906-913): emb [B,D] = [sin(t f) | cos(t f)], f [D/2] host table. */
+int mg_step_embed(const int64_t *t, const float *freq, float *emb, int B, int D, void *stream);
+
 /* Gradient of diffuse_trace (model/diffusion.py:167-175) w.r.t. x_start [B,L,M]: g is the stack [T+1,B,L,M] of the
  * gradients of the T+1 trace entries (entry 0 = clamped normalised x_start, entry t+1 = q_sample at step t); keep
  * uint8 [B,L] (0 = padded frame) or NULL; sqrt_alphas_cumprod [T]. */

@@ -22,7 +22,7 @@ EXPORTS = (
     "mg_step_mlp_fwd", "mg_step_mlp_bwd", "mg_linear_small_fwd", "mg_linear_small_bwd",
     "mg_loss_sum", "mg_loss_grad", "mg_mel_l1_fwd", "mg_mel_l1_bwd", "mg_attention_fwd", "mg_attention_fwd_f16", "mg_layernorm_cm_fwd",
     "mg_length_regulate_fwd", "mg_length_regulate_bwd", "mg_word_pool_fwd", "mg_word_pool_bwd", "mg_mapping_mask",
-    "mg_rel_coef",
+    "mg_rel_coef", "mg_resblock_fwd", "mg_gate_bwd", "mg_mish_fwd", "mg_mish_bwd", "mg_step_embed",
 )
 
 
@@ -125,6 +125,11 @@ def _declare(L):
         "mg_word_pool_bwd": (i, [vp, vp, vp, vp, i, i, i, i, i, i, vp]),
         "mg_mapping_mask": (i, [vp, vp, vp, vp, i, i, i, i, vp]),
         "mg_rel_coef": (i, [vp, vp, vp, vp, i, i, i, vp]),
+        "mg_resblock_fwd": (i, [vp] * 16 + [i, i, i, i, vp]),
+        "mg_gate_bwd": (i, [vp, vp, vp, vp, i, i, i, vp]),
+        "mg_mish_fwd": (i, [vp, vp, sz, vp]),
+        "mg_mish_bwd": (i, [vp, vp, vp, sz, vp]),
+        "mg_step_embed": (i, [vp, vp, vp, i, i, vp]),
         "mg_profile_begin": (i, [i]),
         "mg_profile_begin_sampled": (i, [i, i]),
         "mg_profile_end": (i, [vp, i]),

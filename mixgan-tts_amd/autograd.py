@@ -54,14 +54,16 @@ def spec_affine(x, spec_min, spec_max, norm):
 
 
 class DenoiserFn(torch.autograd.Function):
-    """Denoiser.forward with activations saved in the module's workspace; backward = mg_denoiser_bwd."""
+    """Denoiser.forward with the layer activations saved in a workspace that this node keeps alive (a later forward
+    of the module at any shape, or a cache eviction, cannot take it away); backward = mg_denoiser_bwd."""
 
     @staticmethod
     def forward(ctx, module, x, t, cond, spk, *params):
         _require_cuda(x, cond)
         out = module.run(x, t, cond, spk, save=True)
         ctx.module = module
-        ctx.gen = module._save_gen
+        ctx.ws = module.last_ws
+        ctx.gen = ctx.ws._mg_gen
         ctx.save_for_backward(x, t, cond, spk if spk is not None else x.new_empty(0))
         ctx.has_spk = spk is not None
         return out
@@ -71,7 +73,7 @@ class DenoiserFn(torch.autograd.Function):
         x, t, cond, spk = ctx.saved_tensors
         need = ctx.needs_input_grad
         d_x, d_cond, d_spk, pg = ctx.module.run_backward(g.contiguous(), x, t, cond, spk if ctx.has_spk else None,
-                                                         ctx.gen, need[1], need[3], need[4])
+                                                         ctx.ws, ctx.gen, need[1], need[3], need[4])
         return (None, d_x, None, d_cond, d_spk) + tuple(pg)
 
 
@@ -211,6 +213,67 @@ class _CatTransposeFn(torch.autograd.Function):
 def cat_transpose(a, b):
     _require_cuda(a, b)
     return _CatTransposeFn.apply(a, b)
+
+
+class _ResBlockFn(torch.autograd.Function):
+    """One gated residual block (model/blocks.py:1157-1176) stand-alone: forward = the fused layer kernel the Denoiser
+    launches per layer (mg_resblock_fwd), backward = the same data-gradient / weight-gradient GEMMs mg_denoiser_bwd
+    uses, one layer's worth.  hvec = Wd s (+ Wp spk) and dvec = Wd s are inputs (their Linear layers are separate
+    autograd nodes)."""
+
+    @staticmethod
+    def forward(ctx, x, cond, hvec, dvec, Wc, bc, W3, b3, Wo, bo):
+        _require_cuda(x, cond)
+        x, cond = x.contiguous(), cond.contiguous()
+        save = any(ctx.needs_input_grad)
+        x_out, skip, saves = ops.resblock_fwd(
+            x, cond, ops.pack_cached(Wc), ops.pack_cached(W3, ops.PACK_GATE), ops.pack_cached(Wo), bc.detach(),
+            b3.detach(), bo.detach(), hvec.detach().contiguous(), dvec.detach().contiguous(), save)
+        if save:
+            ctx.save_for_backward(cond, Wc, W3, Wo, *saves)
+        return x_out, skip
+
+    @staticmethod
+    def backward(ctx, g_x, g_skip):
+        cond, Wc, W3, Wo, h, g, sig, tnh = ctx.saved_tensors
+        C, H = Wc.shape[0], Wc.shape[1]
+        rs2 = 0.70710678118654752440
+        g_xs = (g_x * rs2).contiguous()                     # d/d(x + Wd s) through the residual
+        dout = torch.cat([g_xs, g_skip.contiguous()], 1)   # gradient of o = Wo g + bo, [B, 2C, L]
+        dg = ops.conv1d_packed(dout, ops.pack_cached(Wo, ops.PACK_DGRAD), None, C, 1)
+        dz = ops.gate_bwd(dg, sig, tnh)
+        dh = ops.conv1d_packed(dz, ops.pack_cached(W3, ops.PACK_DGRAD), None, C, 3, 1, 1)
+        need = ctx.needs_input_grad
+        dx = ops.conv1d_packed(dz, ops.pack_cached(W3, ops.PACK_DGRAD), None, C, 3, 1, 1, add=g_xs) if need[0] else None
+        dcond = ops.conv1d_packed(dh, ops.pack_cached(Wc, ops.PACK_DGRAD), None, H, 1) if need[1] else None
+        return (dx, dcond,
+                ops.rowsum(dh, per_batch=True) if need[2] else None,
+                ops.rowsum(g_xs, per_batch=True) if need[3] else None,
+                ops.conv1d_wgrad(dh, cond, 1) if need[4] else None, ops.rowsum(dh) if need[5] else None,
+                ops.conv1d_wgrad(dz, h, 3, 1, 1) if need[6] else None, ops.rowsum(dz) if need[7] else None,
+                ops.conv1d_wgrad(dout, g, 1) if need[8] else None, ops.rowsum(dout) if need[9] else None)
+
+
+def residual_block(x, cond, hvec, dvec, Wc, bc, W3, b3, Wo, bo):
+    return _ResBlockFn.apply(x, cond, hvec, dvec, Wc, bc, W3, b3, Wo, bo)
+
+
+class _MishFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_cuda(x)
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return ops.mish_fwd(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.mish_bwd(g.contiguous(), x)
+
+
+def mish(x):
+    return _MishFn.apply(x)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -8,7 +8,7 @@ packing the kernels consume is a derived cache owned by the calling module.
 
 Compute goes through the HIP library only.  The fused Denoiser path does not call these
 modules' forward(); the stand-alone forward()s below exist for drop-in use of a single layer
-and route through the same conv kernel.
+and route through the same kernels (ResidualBlock: the fused layer kernel itself).
 """
 import math
 
@@ -75,10 +75,12 @@ class LinearNorm(nn.Module):
 
 
 class Mish(nn.Module):
-    """Parameter-free marker (model/blocks.py:894-896); evaluated inside the step-MLP kernel."""
+    """x * tanh(softplus(x)) (model/blocks.py:894-896).  Inside the Denoiser it is evaluated by the step-MLP kernel;
+    called on its own it runs mg_mish_fwd / mg_mish_bwd."""
 
     def forward(self, x):
-        raise RuntimeError("Mish is fused into the HIP step-MLP kernel; call the owning module")
+        from . import autograd as ag
+        return ag.mish(x)
 
 
 class DiffusionEmbedding(nn.Module):
@@ -95,7 +97,11 @@ class DiffusionEmbedding(nn.Module):
         return torch.exp(torch.arange(half) * -emb).to(device)
 
     def forward(self, x):
-        raise RuntimeError("DiffusionEmbedding is fused into the HIP step-MLP kernel; call the owning module")
+        """x: diffusion steps [B] (int64 in the reference's callers) -> [B, dim] = cat(sin, cos) (mg_step_embed)."""
+        if not x.is_cuda:
+            from . import _lib
+            raise _lib.MixganHipError("DiffusionEmbedding.forward on %s: the HIP path has no CPU fallback" % x.device)
+        return ops.step_embed(x.to(torch.int64).contiguous(), self.frequencies(x.device).contiguous())
 
 
 class ResidualBlock(nn.Module):
@@ -112,5 +118,14 @@ class ResidualBlock(nn.Module):
         self.conditioner_projection = ConvNorm(d_encoder, residual_channels, kernel_size=1)
         self.output_projection = ConvNorm(residual_channels, 2 * residual_channels, kernel_size=1)
 
-    def forward(self, *a, **k):
-        raise RuntimeError("ResidualBlock runs fused inside Denoiser.forward (mg_denoiser_fwd)")
+    def forward(self, x, conditioner, diffusion_step, speaker_emb, mask=None):
+        """x [B,C,L], conditioner [B,H,L], diffusion_step [B,C], speaker_emb [B,H]|None -> ((x + residual)/sqrt2, skip)
+        (model/blocks.py:1157-1176).  The Denoiser runs all its layers through mg_denoiser_fwd; this stand-alone form
+        launches the same fused layer kernel once, with autograd."""
+        from . import autograd as ag
+        d = ag.linear_small(diffusion_step, self.diffusion_projection.linear.weight)
+        hvec = d + ag.linear_small(speaker_emb, self.speaker_projection.linear.weight) if self.multi_speaker else d
+        return ag.residual_block(x, conditioner, hvec, d,
+                                 self.conditioner_projection.conv.weight, self.conditioner_projection.conv.bias,
+                                 self.conv_layer.conv.weight, self.conv_layer.conv.bias,
+                                 self.output_projection.conv.weight, self.output_projection.conv.bias)

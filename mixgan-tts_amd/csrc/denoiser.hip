@@ -373,6 +373,77 @@ static inline void prof_mark(hipStream_t st, int which)
     }
 }
 
+// ------------------------------------------------------------------------------------------ one fused layer
+// Tile width: 64 frames unless that leaves more than ~1/4 of the 256 CUs without a workgroup AND a
+// narrow tiling still fits one workgroup per CU (a second round would cost more than it gains).
+static void launch_res_layer(ResArgs &a, int B, int L, bool save, bool vec4, hipStream_t st)
+{
+    const long w64 = (long)mg_cdiv(L, RB_NT) * B, w30 = (long)mg_cdiv(L, 30) * B, w32 = (long)mg_cdiv(L, 32) * B;
+    int ntile = w64 > 192 ? 64 : (w30 <= 256 ? 30 : (w32 <= 256 ? 32 : 64));
+    if (const char *force = std::getenv("MG_RB_TILE")) {   // tests pin each tile width against the fixtures
+        const int f = std::atoi(force);
+        if (f == 64 || f == 30 || f == 32) ntile = f;
+    }
+    a.tiles_per_b = mg_cdiv(L, ntile);
+    dim3 grid((unsigned)(a.tiles_per_b * B));
+#define MG_RB_LAUNCH(V, S, N) hipLaunchKernelGGL((resblock_fused_kernel<V, S, N>), grid, dim3(512), 0, st, a)
+    if (ntile == 64) {
+        if (save) {
+            if (vec4) MG_RB_LAUNCH(true, true, 64);
+            else MG_RB_LAUNCH(false, true, 64);
+        } else {
+            if (vec4) MG_RB_LAUNCH(true, false, 64);
+            else MG_RB_LAUNCH(false, false, 64);
+        }
+    } else if (ntile == 30) {
+        if (save) MG_RB_LAUNCH(false, true, 30);
+        else MG_RB_LAUNCH(false, false, 30);
+    } else {
+        if (save) MG_RB_LAUNCH(false, true, 32);
+        else MG_RB_LAUNCH(false, false, 32);
+    }
+#undef MG_RB_LAUNCH
+}
+
+// ResidualBlock.forward stand-alone (model/blocks.py:1157-1176): the same fused kernel on one layer's packed
+// weights.  hvec = Wd s (+ Wp spk), dvec = Wd s (computed by the caller with mg_linear_small_fwd); x_out and skip
+// are written (not accumulated); the four saves are all given (training) or all NULL.
+extern "C" int mg_resblock_fwd(const float *x, const float *cond, const float *wc_packed, const float *w3_packed,
+                               const float *wo_packed, const float *bc, const float *b3, const float *bo,
+                               const float *hvec, const float *dvec, float *x_out, float *skip, float *h_save,
+                               float *g_save, float *sig_save, float *tnh_save, int B, int C, int H, int L, void *stream)
+{
+    if (!x || !cond || !wc_packed || !w3_packed || !wo_packed || !bc || !b3 || !bo || !hvec || !dvec || !x_out || !skip)
+        return MG_ERR_ARG;
+    const int nsave = (h_save != nullptr) + (g_save != nullptr) + (sig_save != nullptr) + (tnh_save != nullptr);
+    if (nsave != 0 && nsave != 4) return MG_ERR_ARG;
+    if (x_out == x) return MG_ERR_ARG;   // neighbouring tiles read each other's halo frames of x
+    if (B <= 0 || L <= 0 || C != RB_C || H != RB_C) return MG_ERR_SHAPE;
+    ResArgs a;
+    a.cond = cond;
+    a.x_in = x;
+    a.x_out = x_out;
+    a.skip = skip;
+    a.wc = wc_packed;
+    a.w3 = w3_packed;
+    a.wo = wo_packed;
+    a.bc = bc;
+    a.b3 = b3;
+    a.bo = bo;
+    a.hvec = hvec;
+    a.dvec = dvec;
+    a.h_save = h_save;
+    a.g_save = g_save;
+    a.sig_save = sig_save;
+    a.tnh_save = tnh_save;
+    a.L = L;
+    a.first = 1;
+    const bool vec4 = (L % 4 == 0) && (((uintptr_t)cond & 15) == 0);
+    launch_res_layer(a, B, L, nsave == 4, vec4, (hipStream_t)stream);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
+}
+
 // ------------------------------------------------------------------------------------------ forward
 extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, const float *x_t, const int64_t *t,
                                const float *cond, const float *spk, float *out, float *ws, size_t ws_floats, int B,
@@ -475,34 +546,8 @@ extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, c
             a.tnh_save = save ? ws + w.tnh + (size_t)l * w.act_stride : nullptr;
             a.L = L;
             a.first = (l == 0);
-            // Tile width: 64 frames unless that leaves more than ~1/4 of the 256 CUs without a workgroup AND a
-            // narrow tiling still fits one workgroup per CU (a second round would cost more than it gains).
-            const long w64 = (long)mg_cdiv(L, RB_NT) * B, w30 = (long)mg_cdiv(L, 30) * B, w32 = (long)mg_cdiv(L, 32) * B;
-            int ntile = w64 > 192 ? 64 : (w30 <= 256 ? 30 : (w32 <= 256 ? 32 : 64));
-            if (const char *force = std::getenv("MG_RB_TILE")) {   // tests pin each tile width against the fixtures
-                const int f = std::atoi(force);
-                if (f == 64 || f == 30 || f == 32) ntile = f;
-            }
-            a.tiles_per_b = mg_cdiv(L, ntile);
-            dim3 grid((unsigned)(a.tiles_per_b * B));
             prof_mark(st, 0);
-#define MG_RB_LAUNCH(V, S, N) hipLaunchKernelGGL((resblock_fused_kernel<V, S, N>), grid, dim3(512), 0, st, a)
-            if (ntile == 64) {
-                if (save) {
-                    if (vec4) MG_RB_LAUNCH(true, true, 64);
-                    else MG_RB_LAUNCH(false, true, 64);
-                } else {
-                    if (vec4) MG_RB_LAUNCH(true, false, 64);
-                    else MG_RB_LAUNCH(false, false, 64);
-                }
-            } else if (ntile == 30) {
-                if (save) MG_RB_LAUNCH(false, true, 30);
-                else MG_RB_LAUNCH(false, false, 30);
-            } else {
-                if (save) MG_RB_LAUNCH(false, true, 32);
-                else MG_RB_LAUNCH(false, false, 32);
-            }
-#undef MG_RB_LAUNCH
+            launch_res_layer(a, B, L, save != 0, vec4, st);
             prof_mark(st, 1);
             MG_LAUNCH_CHECK();
             float *tmp = (l == 0) ? xc : xa;  // after layer 0 the pair is (ws.y, ws.x)

@@ -134,3 +134,69 @@ extern "C" int mg_linear_small_bwd(const float *g, const float *x, const float *
     if (dx) MG_TRY(linear_t(W, g, dx, B, N, K, st));
     return MG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// stand-alone pieces of the denoiser's small modules (model/blocks.py:894-913, :1170-1171)
+// ---------------------------------------------------------------------------------------------
+// dz[b, c, l] = dg * tanh * sig (1 - sig), dz[b, C + c, l] = dg * sig (1 - tanh^2): derivative of
+// g = sigmoid(z[:C]) * tanh(z[C:]) through the values the forward saved
+__global__ void gate_bwd_kernel(const float *__restrict__ dg, const float *__restrict__ sig, const float *__restrict__ tnh,
+                                float *__restrict__ dz, int CL, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / CL, r = i - b * CL;
+        const float g = dg[i], s = sig[i], t = tnh[i];
+        dz[b * 2 * CL + r] = g * t * s * (1.f - s);
+        dz[b * 2 * CL + CL + r] = g * s * (1.f - t * t);
+    }
+}
+
+extern "C" int mg_gate_bwd(const float *dg, const float *sig, const float *tnh, float *dz, int B, int C, int L, void *stream)
+{
+    if (!dg || !sig || !tnh || !dz) return MG_ERR_ARG;
+    if (B <= 0 || C <= 0 || L <= 0) return MG_ERR_SHAPE;
+    const size_t n = (size_t)B * C * L;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dg, sig, tnh, dz, C * L, n);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
+}
+
+__global__ void mish_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        y[i] = v * tanhf(mg_softplus(v));
+    }
+}
+
+extern "C" int mg_mish_fwd(const float *x, float *y, size_t n, void *stream)
+{
+    if (!x || !y) return MG_ERR_ARG;
+    if (n == 0) return MG_OK;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(mish_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
+}
+
+extern "C" int mg_mish_bwd(const float *gy, const float *x, float *gx, size_t n, void *stream)
+{
+    if (!gy || !x || !gx) return MG_ERR_ARG;
+    if (n == 0) return MG_OK;
+    if (n > 0x7fffffffu) return MG_ERR_SHAPE;
+    hipLaunchKernelGGL(mish_bwd_kernel, dim3(mg_cdiv((int)n, 256)), dim3(256), 0, (hipStream_t)stream, gy, x, gx, (int)n);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
+}
+
+// DiffusionEmbedding.forward (model/blocks.py:906-913): emb [B, D] = [sin(t f) | cos(t f)], f [D/2] from the host
+extern "C" int mg_step_embed(const int64_t *t, const float *freq, float *emb, int B, int D, void *stream)
+{
+    if (!t || !freq || !emb) return MG_ERR_ARG;
+    if (B <= 0 || D <= 0 || D % 2) return MG_ERR_SHAPE;
+    hipLaunchKernelGGL(step_embed_kernel, dim3(mg_cdiv(B * (D / 2), 256)), dim3(256), 0, (hipStream_t)stream, t, freq, emb,
+                       B, D);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
+}

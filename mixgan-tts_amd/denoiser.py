@@ -1,6 +1,7 @@
 """Denoiser (model/modules.py:382-446): same constructor, state_dict keys and forward
 signature as the reference; the forward is one call into `mg_denoiser_fwd`."""
 import ctypes
+from collections import OrderedDict
 
 import torch
 from torch import nn
@@ -40,9 +41,10 @@ class Denoiser(nn.Module):
         self._dims = DenoiserDims(residual_layers, residual_channels, d_encoder, n_mel_channels, int(self.multi_speaker))
         self._packed = None
         self._packed_key = None
-        self._ws = {}
-        self._bws = {}
+        self._ws = OrderedDict()      # (B, L, save, device) -> workspace, least recently used first
+        self._bws = OrderedDict()
         self._save_gen = 0
+        self._grad_sink = None        # (flat buffer, {id(param): offset}) bound by distributed.GradBucket
         # "fp32": exact fp32 MFMA everywhere.  "bf16x3": inference-only forward whose residual-layer
         # GEMMs run as 3-term bf16-split products on the bf16 MFMA (fp32-grade, ~1e-5 relative);
         # grad-enabled forwards always take the fp32 path (the backward consumes fp32 activations).
@@ -87,26 +89,44 @@ class Denoiser(nn.Module):
             self._packed_key = key
         return self._packed
 
+    def new_workspace(self, B, L, save, dev):
+        """A private workspace (not cached): for owners that keep raw pointers into it across calls, e.g. a captured
+        hipGraph, which must hold the tensor for as long as the graph lives."""
+        n = _lib.lib().mg_denoiser_workspace_floats(ctypes.byref(self._dims), B, L, int(save))
+        return torch.empty(n, device=dev, dtype=torch.float32)
+
     def _workspace(self, B, L, save, dev):
+        """Cached per shape.  The cache only saves re-allocation: whoever needs a workspace to outlive the call (a
+        pending backward: autograd.DenoiserFn keeps it in ctx; a captured graph: new_workspace) holds the tensor
+        itself, so evicting an entry never frees memory that is still referenced.  A save=True workspace whose
+        backward has not run yet (`_mg_busy`) is not handed out again: the next grad-enabled forward gets a fresh one."""
         k = (B, L, bool(save), dev)
         ws = self._ws.get(k)
-        if ws is None:
-            n = _lib.lib().mg_denoiser_workspace_floats(ctypes.byref(self._dims), B, L, int(save))
-            if len(self._ws) > 8:
-                self._ws.clear()
-            ws = torch.empty(n, device=dev, dtype=torch.float32)
-            self._ws[k] = ws
+        if ws is not None and not (save and getattr(ws, "_mg_busy", False)):
+            self._ws.move_to_end(k)
+            return ws
+        ws = self.new_workspace(B, L, save, dev)
+        self._ws[k] = ws
+        self._ws.move_to_end(k)
+        while len(self._ws) > 8:
+            self._ws.popitem(last=False)
         return ws
 
     # ------------------------------------------------------------------ forward
-    def run(self, x_t, t, cond, spk, out=None, save=False, packed=None):
-        """x_t [B,M,L], t int64 [B], cond [B,H,L] contiguous, spk [B,H]|None -> [B,M,L] (no autograd)."""
+    def run(self, x_t, t, cond, spk, out=None, save=False, packed=None, ws=None):
+        """x_t [B,M,L], t int64 [B], cond [B,H,L] contiguous, spk [B,H]|None -> [B,M,L] (no autograd).
+        ws: explicit workspace (default: the per-shape cache).  With save=True the workspace that now holds the
+        layer activations is left in `self.last_ws` for the caller to keep until its backward."""
         B, M, L = x_t.shape
         if packed is None:
             packed = self.packed_weights(with_backward=save)
-        ws = self._workspace(B, L, save, x_t.device)
+        if ws is None:
+            ws = self._workspace(B, L, save, x_t.device)
         if save:
             self._save_gen += 1
+            ws._mg_busy = True
+            ws._mg_gen = self._save_gen
+            self.last_ws = ws
         if out is None:
             out = torch.empty_like(x_t)
         mode = 1 if save else (2 if self.precision == "bf16x3" else 0)
@@ -132,41 +152,77 @@ class Denoiser(nn.Module):
         return self.run(x, t, cond, spk)[:, None]
 
     # ------------------------------------------------------------------ backward (autograd.DenoiserFn)
-    def run_backward(self, g_out, x_t, t, cond, spk, gen, want_dx, want_dcond, want_dspk):
-        """Returns (d_x_t, d_cond, d_spk, [param grads in weight-table order, None entries skipped])."""
-        if gen != self._save_gen:
+    # ------------------------------------------------------------------ gradient placement
+    def grad_order(self):
+        """Parameters in the order the backward produces their gradients: the 8 head / tail tensors, then each
+        per-layer kind for all layers (mg_denoiser_bwd writes every kind as ONE layer-major array).  A
+        distributed.GradBucket laid out in this order lets the backward write straight into the all-reduce
+        buffer: no per-parameter gather copy (148 small launches per step otherwise)."""
+        table = self._weight_table()
+        head = [p for p in table[:8] if p is not None]
+        per_layer = [table[8 + 9 * l: 8 + 9 * (l + 1)] for l in range(len(self.residual_layers))]
+        kinds = [[lay[j] for lay in per_layer] for j in range(9)]
+        return head + [p for kind in kinds for p in kind if p is not None]
+
+    def bind_grad_buffer(self, flat, offsets):
+        """flat: fp32 buffer; offsets: {id(param): element offset}.  Used only when every kind is layer-contiguous."""
+        table = self._weight_table()
+        NL = len(self.residual_layers)
+        for j in range(9):
+            ps = [table[8 + 9 * l + j] for l in range(NL)]
+            if ps[0] is None:
+                continue
+            for l in range(NL):
+                if id(ps[l]) not in offsets or offsets[id(ps[l])] != offsets[id(ps[0])] + l * ps[0].numel():
+                    raise _lib.MixganHipError("bind_grad_buffer: parameters are not laid out in grad_order()")
+        self._grad_sink = (flat, dict(offsets))
+
+    def _grad_targets(self, dev):
+        """(head grads [8], per-kind layer-major arrays [9]) -- views of the bound bucket when every parameter's
+        .grad is unset (autograd then adopts the returned views as .grad without a copy), fresh tensors otherwise
+        (a second backward before zero_grad must ADD to .grad, which autograd does from a separate tensor)."""
+        table = self._weight_table()
+        NL = len(self.residual_layers)
+        sink = self._grad_sink
+        use_sink = (sink is not None and sink[0].device == dev
+                    and all(p is None or (p.grad is None and id(p) in sink[1]) for p in table))
+        def alloc(p, lead=()):
+            if p is None:
+                return None
+            if use_sink:
+                off = sink[1][id(p)]
+                n = p.numel() * (lead[0] if lead else 1)
+                return sink[0][off:off + n].view(*lead, *p.shape)
+            return torch.empty(*lead, *p.shape, device=dev, dtype=torch.float32)
+        return [alloc(p) for p in table[:8]], [alloc(table[8 + j], (NL,)) for j in range(9)]
+
+    def run_backward(self, g_out, x_t, t, cond, spk, ws, gen, want_dx, want_dcond, want_dspk):
+        """Returns (d_x_t, d_cond, d_spk, [param grads in weight-table order, None entries skipped]).
+        ws: the workspace the grad-enabled forward filled (kept alive by the autograd node)."""
+        if getattr(ws, "_mg_gen", None) != gen:
             raise _lib.MixganHipError(
-                "Denoiser backward: the saved activations were overwritten by a later forward of the same "
-                "module (call backward before the next grad-enabled forward, as train.py does)")
+                "Denoiser backward: the saved activations were overwritten by a later forward into the same workspace")
         L_ = _lib.lib()
         B, M, L = x_t.shape
         dev = x_t.device
         d = self._dims
-        NL, C, H = d.n_layers, d.channels, d.cond_channels
+        NL = d.n_layers
         packed = self.packed_weights(with_backward=True)
-        ws = self._workspace(B, L, True, dev)
         k = (B, L, dev)
         bws = self._bws.get(k)
         if bws is None:
-            if len(self._bws) > 4:
-                self._bws.clear()
+            # transient scratch of this call only (stream-ordered), so eviction is always safe
             bws = torch.empty(L_.mg_denoiser_bwd_workspace_floats(ctypes.byref(d), B, L), device=dev)
             self._bws[k] = bws
-        table = self._weight_table()
-        new = lambda p: torch.empty_like(p)
-        grads = [new(p) if p is not None else None for p in table[:8]]
+            while len(self._bws) > 4:
+                self._bws.popitem(last=False)
+        else:
+            self._bws.move_to_end(k)
+        head, kinds = self._grad_targets(dev)
         # per-layer gradients are slices of layer-major tensors: mg_denoiser_bwd computes them for all layers at once
-        g_w3 = torch.empty(NL, 2 * C, C, 3, device=dev)
-        g_b3 = torch.empty(NL, 2 * C, device=dev)
-        g_wo = torch.empty(NL, 2 * C, C, 1, device=dev)
-        g_bo = torch.empty(NL, 2 * C, device=dev)
-        g_wd = torch.empty(NL, C, C, device=dev)
-        g_wc = torch.empty(NL, C, H, 1, device=dev)
-        g_bc = torch.empty(NL, C, device=dev)
-        g_wp = torch.empty(NL, C, H, device=dev) if self.multi_speaker else None
-        for l, blk in enumerate(self.residual_layers):
-            grads += [g_w3[l], g_b3[l], g_wd[l], g_wc[l], g_bc[l], g_wo[l], g_bo[l],
-                      g_wp[l] if self.multi_speaker else None, None]
+        grads = list(head)
+        for l in range(NL):
+            grads += [None if a is None else a[l] for a in kinds]
         ptrs = (ctypes.c_void_p * len(grads))(*[None if g is None else g.data_ptr() for g in grads])
         d_x = torch.empty_like(x_t) if want_dx else None
         d_cond = torch.empty_like(cond) if want_dcond else None
@@ -174,4 +230,5 @@ class Denoiser(nn.Module):
         check(L_.mg_denoiser_bwd(ctypes.byref(d), fptr(packed), fptr(g_out), fptr(x_t), fptr(cond),
                                  fptr(spk, not self.multi_speaker), fptr(ws), fptr(bws), bws.numel(), ptrs,
                                  fptr(d_x, True), fptr(d_cond, True), fptr(d_spk, True), B, L, stream_ptr()))
+        ws._mg_busy = False
         return d_x, d_cond, d_spk, [g for g in grads if g is not None]

@@ -7,6 +7,8 @@ Differences a caller can see (all opt-in or documented in DESIGN.md):
     the reference's exact draws (GPU and CPU generators differ); `t_fn` likewise for randint;
   * `sampling(noise=None, keep_trace=True)`: keep_trace=False returns only the final mel
     instead of the reference's T+1 retained tensors (SURVEY.md section 8 a8);
+  * `use_graph` (attribute, default False): the inference branch of forward() replays its T-step loop as one
+    captured hipGraph;
   * no tqdm progress bars in the sampling loop (they force a host iteration per step).
 """
 import json
@@ -44,6 +46,9 @@ class GaussianDiffusion(nn.Module):
         self.register_buffer("spec_max", torch.FloatTensor(stats["spec_max"])[None, None, :keep])
         self.noise_fn = None
         self.t_fn = None
+        # inference through forward(): replay the T-step loop as one captured hipGraph (BASELINE configs[2]);
+        # synthesize.py-style callers set `model.diffusion.use_graph = True` once
+        self.use_graph = False
         self.cond = None
         self.spk_emb = None
 
@@ -158,7 +163,9 @@ class GaussianDiffusion(nn.Module):
             st = {"key": key, "x": [torch.empty_like(x_start), torch.empty_like(x_start)],
                   "x0": torch.empty_like(x_start), "noise": torch.empty_like(x_start),
                   "cond": torch.empty_like(cond), "spk": None if spk is None else torch.empty_like(spk),
-                  "ts": [torch.full((B,), i, device=dev, dtype=torch.long) for i in range(T)]}
+                  "ts": [torch.full((B,), i, device=dev, dtype=torch.long) for i in range(T)],
+                  # the graph bakes in raw pointers: it owns its workspace and holds the packed weights it captured
+                  "ws": den.new_workspace(B, L, False, dev), "packed": packed}
             st["cond"].copy_(cond)
             if spk is not None:
                 st["spk"].copy_(spk)
@@ -167,7 +174,7 @@ class GaussianDiffusion(nn.Module):
             def loop():
                 cur = 0
                 for i in reversed(range(T)):
-                    den.run(st["x"][cur], st["ts"][i], st["cond"], st["spk"], out=st["x0"], packed=packed)
+                    den.run(st["x"][cur], st["ts"][i], st["cond"], st["spk"], out=st["x0"], packed=packed, ws=st["ws"])
                     st["noise"].normal_()
                     ops.posterior_sample(st["x0"], st["x"][cur], st["ts"][i], st["noise"], None, buf, clip=True,
                                          out=st["x"][cur ^ 1])
@@ -237,7 +244,7 @@ class GaussianDiffusion(nn.Module):
                 t = torch.full((B,), self.num_timesteps - 1, device=dev, dtype=torch.long)
                 noise = self.diffuse_fn(coarse_mel, t, keep=keep)
             # final mel: denorm + [B,M,L]->[B,L,M] + mask multiply (:164,:200) fused in one transpose kernel
-            x_0_pred = self.sampling(noise=noise, keep_trace=False, _final_keep=keep)[-1]
+            x_0_pred = self.sampling(noise=noise, keep_trace=False, use_graph=self.use_graph, _final_keep=keep)[-1]
             return x_0_pred, x_t, x_t_prev, x_t_prev_pred, t
         M, L = mel.shape[2], mel.shape[1]
         t = self._randint(B, dev)

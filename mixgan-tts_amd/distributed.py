@@ -18,28 +18,44 @@ def is_distributed():
 
 
 class GradBucket:
-    """Flat fp32 view of the gradients of a parameter list; `.grad` of every parameter is made a
-    view into one contiguous buffer so the all-reduce needs no packing copy."""
+    """Flat fp32 buffer holding the gradients of a parameter list, so the all-reduce is one collective with no
+    packing step.  `.grad` of every parameter is (re-)pointed at its slice: producers that know the layout write
+    there directly (Denoiser.bind_grad_buffer: the backward's layer-major gradient arrays ARE slices of `flat`, and
+    autograd adopts them as `.grad` without a copy), every other gradient is copied in by `gather()` in one
+    multi-tensor launch.  `order` (optional) lists parameters in the order they should be laid out; the rest follow."""
 
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, params, order=None):
+        wanted = [p for p in params if p.requires_grad]
+        ids = {id(p) for p in wanted}
+        first = [p for p in (order or []) if id(p) in ids]
+        seen = {id(p) for p in first}
+        self.params = first + [p for p in wanted if id(p) not in seen]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(n, device=dev, dtype=torch.float32)
         self.views = []
+        self.offsets = {}
         off = 0
         for p in self.params:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            self.offsets[id(p)] = off
             off += p.numel()
 
     def gather(self):
-        """Copy (or alias) the current .grad tensors into the flat buffer."""
+        """Make `flat` hold the current gradients and every `.grad` alias its slice.  A parameter without a gradient
+        on this rank (conditionally unused) contributes zeros AND gets `.grad` set, so that after the all-reduce every
+        rank's optimizer steps it with the same averaged gradient (ranks must not diverge)."""
+        src, dst = [], []
         for p, v in zip(self.params, self.views):
             if p.grad is None:
                 v.zero_()
-            elif p.grad.data_ptr() != v.data_ptr():
-                v.copy_(p.grad)
                 p.grad = v
+            elif p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+                p.grad = v
+        if dst:
+            torch._foreach_copy_(dst, src)
         return self.flat
 
     def all_reduce_mean(self, group=None, async_op=False):

@@ -95,8 +95,11 @@ class MixGANTTS(nn.Module):
             output, x_ts, x_t_prevs, x_t_prev_preds, diffusion_step = self.diffusion(mels, output, speaker_emb, mel_masks)
         elif self.model in ["aux", "shallow"]:
             cond = output.clone()
-            if self.model == "aux" and self.training and torch.is_grad_enabled():
-                coarse_mels = self.coarse_mel(output, mel_masks)          # differentiable (aux pre-training)
+            if self.training and torch.is_grad_enabled():
+                # differentiable in aux AND shallow training: the reference detaches only what it hands to the
+                # diffusion and its third return value (:155-160,180); slot 15 keeps the decoder's graph, and
+                # postnet_loss = L1(slot 15, mel) trains decoder / PostNet / encoder in shallow too (model/loss.py:165-167)
+                coarse_mels = self.coarse_mel(output, mel_masks)
             else:
                 with torch.no_grad():
                     coarse_mels = self.coarse_mel(output, mel_masks)

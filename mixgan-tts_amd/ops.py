@@ -393,3 +393,44 @@ def bn_act_bwd_apply(dout, keep, drop_scale, y, x, mean, invstd, gamma, dg, db, 
                                  fptr(invstd), fptr(gamma), fptr(dg), fptr(db), float(inv_count), ACT[act], fptr(dx),
                                  B, C, L, stream_ptr()))
     return dx
+
+
+def resblock_fwd(x, cond, wc_p, w3_p, wo_p, bc, b3, bo, hvec, dvec, save):
+    """mg_resblock_fwd: one fused residual layer.  Returns (x_out, skip, saves) with saves = (h, g, sig, tnh) | None."""
+    L = _lib.lib()
+    B, C, Lf = x.shape
+    H = cond.shape[1]
+    x_out, skip = torch.empty_like(x), torch.empty_like(x)
+    saves = tuple(torch.empty_like(x) for _ in range(4)) if save else None
+    sp = [fptr(t) for t in saves] if save else [fptr(None, True)] * 4
+    check(L.mg_resblock_fwd(fptr(x), fptr(cond), fptr(wc_p), fptr(w3_p), fptr(wo_p), fptr(bc), fptr(b3), fptr(bo),
+                            fptr(hvec), fptr(dvec), fptr(x_out), fptr(skip), *sp, B, C, H, Lf, stream_ptr()))
+    return x_out, skip, saves
+
+
+def gate_bwd(dg, sig, tnh):
+    L = _lib.lib()
+    B, C, Lf = dg.shape
+    dz = torch.empty(B, 2 * C, Lf, device=dg.device, dtype=torch.float32)
+    check(L.mg_gate_bwd(fptr(dg), fptr(sig), fptr(tnh), fptr(dz), B, C, Lf, stream_ptr()))
+    return dz
+
+
+def mish_fwd(x):
+    y = torch.empty_like(x)
+    check(_lib.lib().mg_mish_fwd(fptr(x), fptr(y), x.numel(), stream_ptr()))
+    return y
+
+
+def mish_bwd(gy, x):
+    gx = torch.empty_like(x)
+    check(_lib.lib().mg_mish_bwd(fptr(gy), fptr(x), fptr(gx), x.numel(), stream_ptr()))
+    return gx
+
+
+def step_embed(t, freq):
+    """DiffusionEmbedding: t int64 [B], freq [D/2] -> [B, D]."""
+    B, D = t.shape[0], 2 * freq.shape[0]
+    emb = torch.empty(B, D, device=t.device, dtype=torch.float32)
+    check(_lib.lib().mg_step_embed(iptr(t, torch.int64), fptr(freq), fptr(emb), B, D, stream_ptr()))
+    return emb

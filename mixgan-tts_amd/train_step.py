@@ -25,17 +25,27 @@ class HotPathTrainer:
         self.grad_clip = oc["grad_clip_thresh"]
         self.lambda_fm = train_config["loss"]["lambda_fm" if diffusion.model != "shallow" else "lambda_fm_shallow"]
         self.n_layers = model_config["discriminator"]["n_layer"] + model_config["discriminator"]["n_cond_layer"]
+        if oc.get("grad_acc_step", 1) != 1:
+            raise NotImplementedError("HotPathTrainer steps the optimizers every call (train.py:77-85 with "
+                                      "grad_acc_step = 1, the value every shipped config sets)")
         g_params = list(diffusion.parameters()) + list(extra_g_params)
         self.optG = torch.optim.Adam(g_params, lr=oc["init_lr_G"], betas=oc["betas"])       # utils/model.py:32-40
         self.optD = torch.optim.Adam(discriminator.parameters(), lr=oc["init_lr_D"], betas=oc["betas"])
         self.sdlG = torch.optim.lr_scheduler.ExponentialLR(self.optG, gamma=oc["gamma"])    # stepped per EPOCH
         self.sdlD = torch.optim.lr_scheduler.ExponentialLR(self.optD, gamma=oc["gamma"])
         self.d_loss_fn, self.g_loss_fn = losses.get_adversarial_losses_fn(train_config["loss"]["adv_loss_mode"])
-        self.bucketG = GradBucket(g_params)
+        # the denoiser's backward writes its weight gradients straight into the G bucket (no gather copy)
+        self.bucketG = GradBucket(g_params, order=diffusion.denoise_fn.grad_order())
+        if self.bucketG.flat.is_cuda:
+            diffusion.denoise_fn.bind_grad_buffer(self.bucketG.flat, self.bucketG.offsets)
         self.bucketD = GradBucket(list(discriminator.parameters()))
+
+    grad_hook = None      # optional callable(name, bucket) after the gradient exchange, before clipping (tests, logging)
 
     def _update(self, params, bucket, opt):
         bucket.all_reduce_mean()                      # no-op on one process
+        if self.grad_hook is not None:
+            self.grad_hook("G" if bucket is self.bucketG else "D", bucket)
         torch.nn.utils.clip_grad_norm_(params, self.grad_clip)
         opt.step()
         opt.zero_grad()                               # after step, as train.py:84-85
@@ -51,8 +61,13 @@ class HotPathTrainer:
         halves = lambda maps, k: [m[k * B:(k + 1) * B] for m in maps]  # noqa: E731
         return halves(cond_maps, 0), halves(uncond_maps, 0), halves(cond_maps, 1), halves(uncond_maps, 1)
 
-    def step(self, mel, cond, spk, mel_pad_mask, coarse_mel=None):
-        """One D phase + one G phase on a batch.  mel [B,L,M]; cond [B,L,H]; mel_pad_mask True = pad."""
+    def step(self, mel, cond, spk, mel_pad_mask, coarse_mel=None, extra_loss=None):
+        """One D phase + one G phase on a batch.  mel [B,L,M]; cond [B,L,H]; mel_pad_mask True = pad.
+        extra_loss: added to the generator loss before its backward -- the terms of recon_loss that come from
+        modules upstream of the path (model/loss.py:195: lambda_d * duration + lambda_p * pitch + lambda_e * energy
+        + helper for the linguistic encoder), so an injected encoder trains jointly through this step.
+        shallow: when `coarse_mel` carries gradient (MixGANTTS computes it with grad in training, as the reference
+        does, model/mixgantts.py:140-143), postnet_loss = L1(coarse_mel, mel) joins the loss (model/loss.py:165-167)."""
         G, D = self.G, self.D
         # ---------------- D phase (train.py:133-146)
         # train.py:133 builds (and discards) the generator's autograd graph here; every output is detached
@@ -75,10 +90,18 @@ class HotPathTrainer:
         mel_loss = losses.get_mel_loss(G.denorm_spec(x0), target, mel_pad_mask)
         fm = self.lambda_fm * losses.get_fm_loss(r_c, r_u, f_c, f_u, self.n_layers)
         g_loss = adv + mel_loss + fm
+        out = {}
+        if G.model == "shallow" and coarse_mel is not None and coarse_mel.requires_grad:
+            postnet_loss = losses._L1Fn.apply(coarse_mel, mel[:, :coarse_mel.shape[1], :].contiguous())
+            g_loss = g_loss + postnet_loss
+            out["postnet_loss"] = postnet_loss.detach()
+        if extra_loss is not None:
+            g_loss = g_loss + extra_loss
         g_loss.backward()
         self._update(self.bucketG.params, self.bucketG, self.optG)
-        return {"d_loss": d_loss.detach(), "adv_loss": adv.detach(), "mel_loss": mel_loss.detach(),
-                "fm_loss": fm.detach() if torch.is_tensor(fm) else fm}
+        out.update({"d_loss": d_loss.detach(), "adv_loss": adv.detach(), "mel_loss": mel_loss.detach(),
+                    "fm_loss": fm.detach() if torch.is_tensor(fm) else fm})
+        return out
 
     def end_epoch(self):
         self.sdlG.step()

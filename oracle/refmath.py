@@ -392,6 +392,43 @@ def aux_acoustic_losses(W, buf, x, mel_targets, pad_mask, max_seq_len, T, tape, 
     return mel_loss, F.l1_loss(coarse, target), coarse
 
 
+def mixgantts_forward(W, buf, model, T, enc_out, src_masks, src_w_masks, src_lens, speaker_emb, mels, coarse_training,
+                      tape, drop=None, max_seq_len=1000, p_targets=None):
+    """model/mixgantts.py:55-183 downstream of the linguistic encoder (whose nine outputs `enc_out` are given:
+    model/linguistic_encoder.py:373-383).  Returns ([16 slots], p_targets, coarse_mels) with the reference's
+    detach pattern: in `shallow` the diffusion sees detached cond / speaker / mask / coarse mel, slots 2, 5, 7-11 and
+    the third return value are detached, while slot 15 (`postnet_outputs`) is NOT (:140-143,180) -- it carries the
+    decoder's graph into postnet_loss (model/loss.py:165-167).
+    src_masks / src_w_masks: get_mask_from_lengths of :77-78 (True = valid); mels None = inference;
+    coarse_training: whether Decoder / PostNet run in train mode (dropout masks from `drop`, batch-stat BatchNorm)."""
+    output, p_pred, e_pred, log_d_pred, d_rounded, mel_lens, mel_masks, alignments, logprobs = enc_out
+    det = (lambda a: a.detach() if (a is not None and model == "shallow") else a)
+    mel_masks = ~mel_masks                                  # True = pad from here on (:123,138)
+    x_ts = x_prevs = x_prev_preds = t = None
+    coarse = postnet_outputs = None
+    if model == "naive":
+        output, x_ts, x_prevs, x_prev_preds, t = diffusion_forward(W_sub(W, "diffusion."), buf, model, T, mels, output,
+                                                                   speaker_emb, mel_masks, None, tape)
+    else:
+        cond = output.clone()
+        coarse = coarse_mel(W, output, mel_masks, max_seq_len, training=coarse_training, drop=drop)
+        postnet_outputs = coarse
+        if model == "aux":
+            output = diffuse_trace(buf, coarse, mel_masks[:, :coarse.shape[1]], T, tape)
+        else:
+            output, x_ts, x_prevs, x_prev_preds, t = diffusion_forward(
+                W_sub(W, "diffusion."), buf, model, T, mels, det(cond), det(speaker_emb), det(mel_masks), det(coarse), tape)
+    return [output, (x_ts, x_prevs, x_prev_preds), det(speaker_emb), t, p_pred, det(e_pred), log_d_pred, det(d_rounded),
+            det(src_masks), det(mel_masks), det(src_lens), det(mel_lens), alignments, logprobs, src_w_masks,
+            postnet_outputs], p_targets, det(coarse)
+
+
+def W_sub(W, prefix):
+    """The sub-dict of a flat weight dict under `prefix`, with the prefix stripped."""
+    n = len(prefix)
+    return {k[n:]: v for k, v in W.items() if k.startswith(prefix)}
+
+
 # ----------------------------------------------------------------------------- linguistic-encoder index ops
 # (SURVEY.md section 8 f1: the four host-loop functions of the out-of-scope LinguisticEncoder that
 #  serialise the GPU with one .item() per phoneme.  Plain loops here, like the reference.)

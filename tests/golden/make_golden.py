@@ -56,12 +56,15 @@ def manifest_of(mod):
     return m
 
 
-def seed_module(mod, seed, name):
+def seed_module(mod, seed, name, exclude=None):
     man = manifest_of(mod)
+    if exclude is not None:          # e.g. the injected linguistic encoder of MixGANTTS: its outputs are recorded instead
+        man = {k: v for k, v in man.items() if not k.startswith(exclude)}
+    keep = lambda k: exclude is None or not k.startswith(exclude)  # noqa: E731
     MANIFEST[name] = {"seeded": man,
-                      "state_dict": {k: list(v.shape) for k, v in mod.state_dict().items()},
-                      "state_dict_order": list(mod.state_dict().keys()),
-                      "param_order": [k for k, _ in mod.named_parameters()]}
+                      "state_dict": {k: list(v.shape) for k, v in mod.state_dict().items() if keep(k)},
+                      "state_dict_order": [k for k in mod.state_dict().keys() if keep(k)],
+                      "param_order": [k for k, _ in mod.named_parameters() if keep(k)]}
     w = WR.draw(man, seed)
     sd = mod.state_dict()
     with torch.no_grad():
@@ -140,7 +143,158 @@ def grad_digest(g):
 
 
 # --------------------------------------------------------------------------------------------
+def mixgantts_cases(stats, M):
+    """(a16) MixGANTTS.forward (model/mixgantts.py:55-183) with the REAL LinguisticEncoder on CPU.  The encoder is
+    upstream of the path: its nine outputs are recorded so the product test replays them through a stand-in encoder;
+    every one of the 16 output slots + p_targets + coarse_mels is stored with its None-ness and requires_grad flag,
+    and for the training cases the gradients of a seeded linear functional of the differentiable slots w.r.t. the
+    encoder output and a few weights.  Own RNG streams: adding this case leaves every other fixture unchanged."""
+    import torch.nn.functional as _F
+    from model.mixgantts import MixGANTTS
+    rng = np.random.default_rng(20241101)
+
+    class DropTape:
+        def __init__(self):
+            self.masks = []
+
+        def __call__(self, x, p=0.5, training=True, inplace=False):
+            if not training or p == 0.0:
+                return x
+            keep = torch.from_numpy((rng.random(tuple(x.shape)) >= p).astype(np.float32))
+            self.masks.append(keep.numpy().astype(np.uint8))
+            return x * keep / (1.0 - p)
+
+    def flat_slots(out, p_targets, coarse):
+        """name -> tensor|None for every leaf of the return value."""
+        d = {}
+        for i, o in enumerate(out):
+            if isinstance(o, (list, tuple)):
+                for j, oo in enumerate(o):
+                    d["slot%02d/%d" % (i, j)] = oo
+            else:
+                d["slot%02d" % i] = o
+        d["p_targets"], d["coarse_mels"] = p_targets, coarse
+        return d
+
+    B = 2
+    wb = torch.tensor([[2, 1, 3], [4, 2, 0]])
+    src_w_lens = torch.tensor([3, 2])
+    src_lens = wb.sum(1)
+    Tp = int(src_lens.max())
+    for model, ms, train in (("naive", False, True), ("naive", True, True), ("naive", False, False),
+                             ("shallow", False, True), ("shallow", False, False), ("aux", False, True)):
+        name = "mixgantts_%s_ms%d_%s" % (model, int(ms), "train" if train else "infer")
+        print(" ", name)
+        torch.manual_seed(977)                         # the encoder keeps its own (torch-default) initialisation
+        T = 4
+        a, pre, mc, tr = configs(model, T, multi_speaker=ms, stats_dir=stats)
+        pre["preprocessing"]["speaker_embedder"] = "none"      # config/AISHELL3/preprocess.yaml (absent from LJSpeech's)
+        m = MixGANTTS(a, pre, mc, tr)
+        ck = seed_module(m, 61 + int(ms), "mixgantts_%s_ms%d" % (model, int(ms)), exclude="linguistic_encoder.")
+        texts = torch.from_numpy(rng.integers(1, 50, (B, Tp)))
+        dur = torch.from_numpy(rng.integers(1, 6, (B, Tp)))
+        for b in range(B):
+            texts[b, src_lens[b]:] = 0
+            dur[b, src_lens[b]:] = 0
+        speakers = torch.tensor([1, 3])
+        arrs = dict(wsum=ck, texts=texts, src_lens=src_lens, wb=wb, src_w_lens=src_w_lens, speakers=speakers)
+        enc_rec = {}
+
+        def hook(mod, inp, out_):
+            out_[0].retain_grad() if out_[0].requires_grad else None
+            enc_rec["out"] = out_
+        h = m.linguistic_encoder.register_forward_hook(hook)
+        tape = Tape(rng, T)
+        drop = DropTape()
+        saved_dropout = _F.dropout
+        if train:
+            mel_lens = dur.sum(1)
+            Lm = int(mel_lens.max())
+            mels = torch.from_numpy(rng.uniform(-11.5, 2.0, (B, Lm, M)).astype(np.float32))
+            for b in range(B):
+                mels[b, mel_lens[b]:] = 0
+            pitch = torch.from_numpy(rng.standard_normal((B, Tp)).astype(np.float32))
+            energy = torch.from_numpy(rng.standard_normal((B, Tp)).astype(np.float32))
+            attn = torch.from_numpy(rng.uniform(0, 1, (B, Tp, Lm)).astype(np.float32))
+            arrs.update(mels=mels, mel_lens=mel_lens, pitch=pitch, energy=energy, dur=dur)
+            m.train()
+            m.linguistic_encoder.eval()                # its dropout is not replayed (its outputs are recorded)
+            _F.dropout = drop
+            try:
+                with patched_rng(tape):
+                    out, p_targets, coarse = m(speakers, texts, src_lens, Tp, wb, src_w_lens, 3, None, attn, mels, mel_lens,
+                                               Lm, pitch, energy, dur)
+            finally:
+                _F.dropout = saved_dropout
+        else:
+            m.eval()
+            with patched_rng(tape), torch.no_grad():
+                out, p_targets, coarse = m(speakers, texts, src_lens, Tp, wb, src_w_lens, 3, d_control=4.0)
+        h.remove()
+        eo = enc_rec["out"]
+        assert int(eo[5].min()) > 0, "an utterance came out with zero frames: change d_control"
+        for i, o in enumerate(eo):
+            if isinstance(o, (list, tuple)):
+                for j, oo in enumerate(o):
+                    arrs["enc/%d/%d" % (i, j)] = oo
+            elif o is not None:
+                arrs["enc/%d" % i] = o
+        slots = flat_slots(out, p_targets, coarse)
+        flags = {}
+        for k, v in slots.items():
+            flags[k] = -1 if v is None else int(bool(v.requires_grad))
+            if v is not None:
+                arrs[k] = v
+        arrs["flag_names"] = np.array(sorted(flags))
+        arrs["flags"] = np.array([flags[k] for k in sorted(flags)], dtype=np.int64)
+        for i, a_ in enumerate(tape.log):
+            arrs["rng%d" % i] = a_
+        for i, mk in enumerate(drop.masks):
+            arrs["mask%d" % i] = mk
+        if train:
+            # a seeded linear functional of every differentiable slot that is ours to produce
+            total = 0
+            for k in ("slot00", "slot01/2", "slot15"):
+                v = slots.get(k)
+                if k == "slot00" and model == "aux":
+                    for j, tr_ in enumerate(out[0]):
+                        w = torch.from_numpy(rng.standard_normal(tuple(tr_.shape)).astype(np.float32))
+                        arrs["w/slot00/%d" % j] = w
+                        total = total + (tr_ * w).sum()
+                    continue
+                if v is not None and v.requires_grad:
+                    w = torch.from_numpy(rng.standard_normal(tuple(v.shape)).astype(np.float32))
+                    arrs["w/" + k] = w
+                    total = total + (v * w).sum()
+            total.backward()
+            arrs["d_enc_out"] = eo[0].grad
+            picks = ("diffusion.denoise_fn.residual_layers.7.", "diffusion.denoise_fn.output_projection",
+                     "decoder.layer_stack.0.", "decoder.layer_stack.5.pos_ffn", "mel_linear", "postnet.convolutions.0.",
+                     "postnet.convolutions.4.", "speaker_emb")
+            for k, p in m.named_parameters():
+                if k.startswith(picks):
+                    arrs["has_grad/" + k] = np.array(int(p.grad is not None))
+                    if p.grad is not None:
+                        dg, corner = grad_digest(p.grad)
+                        arrs["dw_sum/" + k] = dg
+                        arrs["dw_corner/" + k] = corner
+            if model != "naive":
+                for k, b_ in m.postnet.named_buffers():
+                    arrs["pn_buf/" + k] = b_.detach().numpy().copy()
+        save(name, **arrs)
+
+
 def main():
+    if "--only-mixgantts" in sys.argv:                 # add the (a16) case without re-running the others
+        with open(os.path.join(OUT, "manifest.json")) as f:
+            MANIFEST.update(json.load(f))
+        M = 80
+        stats = H.make_stats_dir(np.linspace(-11.5, -9.0, M), np.linspace(1.0, 2.0, M), n_speakers=5)
+        mixgantts_cases(stats, M)
+        with open(os.path.join(OUT, "manifest.json"), "w") as f:
+            json.dump(MANIFEST, f, indent=0, sort_keys=True)
+        print("manifest written")
+        return
     rng = np.random.default_rng(20240607)
     M = 80
     spec_min = np.linspace(-11.5, -9.0, M)
@@ -627,6 +781,9 @@ def main():
     arrs["so/w_end"], arrs["so/b_end"] = lin.weight.detach().numpy().copy(), lin.bias.detach().numpy().copy()
     arrs["so/init_lr"] = np.array(so.init_lr)
     save("aux_train", **arrs)
+
+    print("mixgantts")
+    mixgantts_cases(stats, M)
 
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(MANIFEST, f, indent=0, sort_keys=True)

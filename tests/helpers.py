@@ -126,3 +126,76 @@ class Tape:
         self.i += 1
         assert tuple(x.shape) == tuple(shape), (tuple(x.shape), tuple(shape))
         return x
+
+
+# ----------------------------------------------------------------------------------------------
+# (a16) MixGANTTS.forward fixtures (tests/golden/mixgantts_*.npz): the recorded outputs of the reference's
+# LinguisticEncoder, the 16 slots + p_targets + coarse_mels with their None-ness / requires_grad flags.
+MIXGANTTS_CASES = [("naive", 0, True), ("naive", 1, True), ("naive", 0, False), ("shallow", 0, True),
+                   ("shallow", 0, False), ("aux", 0, True)]
+
+
+def mixgantts_case_name(model, ms, train):
+    return "mixgantts_%s_ms%d_%s" % (model, ms, "train" if train else "infer")
+
+
+def mixgantts_encoder_outputs(g, train, device=None):
+    """The nine outputs of model/linguistic_encoder.py:373-383 as recorded; in training the float ones require grad,
+    as they do coming out of the reference's encoder."""
+    def one(key):
+        t = T(g[key])
+        if device is not None:
+            t = t.to(device)
+        if train and t.is_floating_point():
+            t.requires_grad_()
+        return t
+    out = []
+    for i in range(9):
+        if ("enc/%d" % i) in g:
+            out.append(one("enc/%d" % i))
+        else:
+            n = len([k for k in g if k.startswith("enc/%d/" % i)])
+            out.append([one("enc/%d/%d" % (i, j)) for j in range(n)])
+    return tuple(out)
+
+
+def mixgantts_leaves(out, p_targets, coarse):
+    """name -> tensor|None for every leaf of MixGANTTS.forward's return value (names as in the fixture)."""
+    d = {}
+    for i, o in enumerate(out):
+        if isinstance(o, (list, tuple)):
+            for j, oo in enumerate(o):
+                d["slot%02d/%d" % (i, j)] = oo
+        else:
+            d["slot%02d" % i] = o
+    d["p_targets"], d["coarse_mels"] = p_targets, coarse
+    return d
+
+
+def assert_mixgantts_slots(leaves, g, tol, check_flags):
+    """Values, None-ness and (in training) requires_grad of every leaf against the fixture."""
+    flags = dict(zip([str(k) for k in g["flag_names"]], [int(v) for v in g["flags"]]))
+    assert sorted(leaves) == sorted(flags), (sorted(leaves), sorted(flags))
+    for k, v in leaves.items():
+        if flags[k] < 0:
+            assert v is None, k + " should be None"
+            continue
+        assert v is not None, k + " is None"
+        ref = g[k]
+        a = v.detach().cpu().numpy()
+        assert a.shape == ref.shape and str(a.dtype) == str(ref.dtype), (k, a.shape, a.dtype, ref.shape, ref.dtype)
+        if a.dtype.kind == "f":
+            fin = np.isfinite(ref)                 # encoder pass-throughs hold log(0) = -inf for padded words
+            assert np.array_equal(a[~fin], ref[~fin], equal_nan=True), k
+            assert_close(np.where(fin, a, 0), np.where(fin, ref, 0), tol, k)
+        else:
+            assert (a == ref).all(), k
+        if check_flags:
+            assert int(v.requires_grad) == flags[k], "%s.requires_grad = %s, reference %d" % (k, v.requires_grad, flags[k])
+
+
+def mixgantts_tapes(g):
+    """(rng draws in call order, dropout keep-masks in call order) of the fixture."""
+    n = len([k for k in g if k.startswith("rng")])
+    m = len([k for k in g if k.startswith("mask")])
+    return [g["rng%d" % i] for i in range(n)], [g["mask%d" % i] for i in range(m)]

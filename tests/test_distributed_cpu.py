@@ -90,3 +90,46 @@ def test_single_process_is_noop():
     assert b.all_reduce_mean() is None
     for p, g in zip(m.parameters(), g0):
         assert torch.equal(p.grad, g)
+
+
+def _unused_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(5)
+        a, b = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)      # `b` is only used on rank 1
+        x = torch.randn(3, 4)
+        y = a(x) + (b(x) if rank == 1 else 0)
+        y.pow(2).mean().backward()
+        params = list(a.parameters()) + list(b.parameters())
+        assert (b.weight.grad is None) == (rank == 0)
+        bucket = GradBucket(params, order=list(b.parameters()))  # a layout order other than the parameter order
+        assert bucket.params[0] is b.weight
+        bucket.all_reduce_mean()
+        assert all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+        opt = torch.optim.Adam(params, lr=0.1)
+        opt.step()
+        q.put((rank, [p.detach().numpy().copy() for p in params]))     # numpy: pickled by value
+    finally:
+        dist.destroy_process_group()
+
+
+def test_parameter_unused_on_one_rank_still_steps_identically():
+    """A parameter without a gradient on one rank contributes zeros to the all-reduce and still gets `.grad` set, so
+    every rank's optimizer applies the same averaged gradient and the replicas cannot drift apart."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_unused_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for w0, w1 in zip(got[0][1], got[1][1]):
+        assert (w0 == w1).all()
+    torch.manual_seed(5)
+    b_init = [p.detach().clone() for p in (torch.nn.Linear(4, 4), torch.nn.Linear(4, 4))[1].parameters()]
+    assert not (got[0][1][2] == b_init[0].numpy()).all()         # rank 0 moved `b` too

@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import golden, T, seeded, assert_close, assert_digest
+from helpers import (golden, T, seeded, assert_close, assert_digest, MIXGANTTS_CASES, mixgantts_case_name,
+                     mixgantts_encoder_outputs, mixgantts_leaves, assert_mixgantts_slots, mixgantts_tapes)
 from oracle import schedule as S, refmath as R
 
 FWD = 2e-6
@@ -291,6 +292,45 @@ def test_aux_train_mode_blocks(manifest):
             assert_close(W[k], g["pn/buf/" + k], 1e-6, k)
         elif not k.endswith("num_batches_tracked"):
             assert_digest(W[k].grad, {kk[3:]: v for kk, v in g.items() if kk.startswith("pn/dw")}, k, 5e-5)
+
+
+@pytest.mark.parametrize("model,ms,train", MIXGANTTS_CASES)
+def test_mixgantts_forward(manifest, model, ms, train):
+    """(a16) model/mixgantts.py:55-183 downstream of the (recorded) linguistic encoder: every output slot, its
+    None-ness and requires_grad, and in training the gradients reaching the encoder output and a few weights."""
+    name = mixgantts_case_name(model, ms, train)
+    g = golden(name)
+    W, ck = seeded(manifest, "mixgantts_%s_ms%d" % (model, ms), 61 + ms, requires_grad=train)
+    np.testing.assert_allclose(ck, g["wsum"], rtol=1e-12)
+    W["decoder.position_enc"] = R.sinusoid_table(1001, 256)[None]          # max_seq_len 1000 (config/LJSpeech/model.yaml)
+    b = _buf(g=golden("elementwise"))
+    enc = mixgantts_encoder_outputs(g, train)
+    src_lens, src_w_lens = T(g["src_lens"]), T(g["src_w_lens"])
+    valid = lambda lens: torch.arange(int(lens.max()))[None, :] < lens[:, None]  # noqa: E731
+    spk = W["speaker_emb.weight"][T(g["speakers"])] if ms else None
+    rng, masks = mixgantts_tapes(g)
+    tape = R.NoiseTape([T(a) for a in rng])
+    mt = _MaskTape({"m/mask%d" % i: a for i, a in enumerate(masks)}, "m")
+    with torch.set_grad_enabled(train):
+        out, p_t, coarse = R.mixgantts_forward(
+            W, b, model, 4, enc, valid(src_lens), valid(src_w_lens), src_lens, spk, T(g["mels"]) if train else None,
+            train, tape, mt if train else None, p_targets=T(g["pitch"]) if train else None)
+    assert tape.i == len(rng) and mt.i == len(masks)
+    leaves = mixgantts_leaves(out, p_t, coarse)
+    assert_mixgantts_slots(leaves, g, 2e-5, check_flags=train)
+    if not train:
+        return
+    total = 0
+    for k in sorted(k for k in g if k.startswith("w/")):
+        total = total + (leaves[k[2:]] * T(g[k])).sum()
+    total.backward()
+    assert_close(enc[0].grad, g["d_enc_out"], 5e-5, "d_enc_out")
+    for k in [k[len("has_grad/"):] for k in g if k.startswith("has_grad/")]:
+        assert (W[k].grad is not None) == bool(g["has_grad/" + k]), k
+        if W[k].grad is not None:
+            assert_digest(W[k].grad, g, k, 1e-4)
+    for k in [k[len("pn_buf/"):] for k in g if k.startswith("pn_buf/") and not k.endswith("num_batches_tracked")]:
+        assert_close(W["postnet." + k], g["pn_buf/" + k], 1e-6, k)
 
 
 def test_scheduled_optim_matches_reference():
