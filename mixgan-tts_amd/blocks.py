@@ -92,9 +92,13 @@ class DiffusionEmbedding(nn.Module):
         self.dim = d_denoiser
 
     def frequencies(self, device=None):
+        """exp(-i ln(1e4) / (half - 1)) of the reference's fp32 products, CORRECTLY ROUNDED to fp32 (exp taken in
+        fp64).  The reference's own `torch.exp` is a ~1-ulp vectorised routine whose last bit depends on the CPU
+        model; one ulp of a frequency is 6e-5 rad at t = 999, so a host-computed table makes T=1000 results differ
+        between machines.  This table is the same everywhere and within that ambiguity of any reference run."""
         half = self.dim // 2
         emb = math.log(10000) / (half - 1)
-        return torch.exp(torch.arange(half) * -emb).to(device)
+        return torch.exp((torch.arange(half) * -emb).double()).float().to(device)
 
     def forward(self, x):
         """x: diffusion steps [B] (int64 in the reference's callers) -> [B, dim] = cat(sin, cos) (mg_step_embed)."""

@@ -210,9 +210,11 @@ static __global__ void step_embed_kernel(const int64_t *__restrict__ t, const fl
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * half) return;
     const int b = idx / half, i = idx - b * half;
-    const float ang = (float)t[b] * freq[i];
-    emb[(size_t)b * C + i] = sinf(ang);
-    emb[(size_t)b * C + half + i] = cosf(ang);
+    // the reference rounds the product to fp32 and takes sin / cos of THAT number; at t ~ 1000 rad the fp32 device
+    // sinf is off by about one ulp of the ANGLE (6e-5), so evaluate in double (B * C/2 values per call: free)
+    const double ang = (double)((float)t[b] * freq[i]);
+    emb[(size_t)b * C + i] = (float)sin(ang);
+    emb[(size_t)b * C + half + i] = (float)cos(ang);
 }
 
 __device__ __forceinline__ float mg_softplus(float v) { return v > 20.f ? v : log1pf(expf(v)); }  // F.softplus defaults

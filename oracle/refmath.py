@@ -17,9 +17,14 @@ def step_embedding(t, dim=256):
     """model/blocks.py:906-913 -- [sin | cos] of t * exp(-i ln(1e4)/(dim/2-1))."""
     half = dim // 2
     rate = math.log(10000) / (half - 1)
-    freq = torch.exp(torch.arange(half, device=t.device) * -rate)
-    ang = t[:, None] * freq[None, :]
-    return torch.cat((ang.sin(), ang.cos()), dim=-1)
+    # The reference takes torch.exp of the fp32 products.  A host's vectorised fp32 exp is only good to ~1 ulp and
+    # differs between CPU models (3 of the 128 entries on the fixture machine are not the correctly rounded value,
+    # other entries on the GPU box's host), and one ulp of a frequency is 6e-5 rad at t = 999.  Restated with the
+    # correctly rounded table (exp in fp64 of the same fp32 products), which is what every host approximates:
+    # 3.4e-6 from the fixture at t = 999, identical on every machine.
+    freq = torch.exp((torch.arange(half, device=t.device) * -rate).double()).float()
+    ang = (t[:, None] * freq[None, :]).double()
+    return torch.cat((ang.sin(), ang.cos()), dim=-1).float()
 
 
 def mish(x):

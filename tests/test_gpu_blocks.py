@@ -49,8 +49,10 @@ def test_residual_block_forward_and_gradients(mg, manifest, ms):
 def test_diffusion_embedding_forward(mg):
     g = golden("step_embedding")
     emb = mg.blocks.DiffusionEmbedding(256)(T(g["t"]).cuda())
-    # sin / cos of arguments up to ~1e3 rad: the device's range reduction differs from glibc's in the last bits
-    assert_close(emb.cpu(), g["emb"], 2e-5, "step embedding")
+    assert_close(emb.cpu()[:3], g["emb"][:3], 1e-6, "step embedding, t <= 3")
+    # t = 99, 999: the frequency table is the correctly rounded one (blocks.DiffusionEmbedding.frequencies), within
+    # one ulp of a frequency (6e-5 rad at t = 999) of whatever host exp the reference run used
+    assert_close(emb.cpu(), g["emb"], 1e-5, "step embedding")
 
 
 def test_mish_forward_backward(mg):

@@ -102,8 +102,14 @@ def test_mixgantts_forward_matches_reference(manifest, tmp_path, model, ms, trai
     params = dict(m.named_parameters())
     for k in [k[len("has_grad/"):] for k in g if k.startswith("has_grad/")]:
         assert (params[k].grad is not None) == bool(g["has_grad/" + k]), k
-        if params[k].grad is not None:
-            assert_digest(params[k].grad, g, k, 2e-4)
+        if params[k].grad is None:
+            continue
+        if k.endswith("w_ks.bias") or (k.startswith("postnet.") and k.endswith("conv.bias")):
+            # exactly zero in theory (softmax is invariant to a shift of every key; batch-statistics BatchNorm
+            # removes a conv bias): rounding noise on both sides, compared by magnitude only
+            assert params[k].grad.abs().sum().item() < 1e-2 and g["dw_sum/" + k][1] < 1e-2, k
+            continue
+        assert_digest(params[k].grad, g, k, 2e-4)
     bufs = dict(m.postnet.named_buffers()) if model != "naive" else {}
     for k in [k[len("pn_buf/"):] for k in g if k.startswith("pn_buf/")]:
         assert_close(bufs[k].float(), g["pn_buf/" + k].astype(np.float32), 1e-5, k)
