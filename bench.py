@@ -125,26 +125,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def single_launch(precision):
+        """Does Denoiser.forward run as the one persistent kernel (csrc/denoiser_persist.h)?  Same rule as the library."""
+        return precision == "fp32" and os.environ.get("MG_DENOISER_PERSIST", "1")[:1] != "0" and (L + 31) // 32 <= 128 \
+            and os.environ.get("MG_DENOISER_GENERIC") is None
+
     def measure(precision):
         den.precision = precision
         pk = den.packed_weights()
 
         def step_(i, xin, xout):
-            t = ts[(T - 1 - i) % T]
-            den.run(xin, t, cond, None, out=x0, packed=pk)
-            noise.normal_()
-            ops.posterior_sample(x0, xin, t, noise, None, buf, clip=True, out=xout)
+            # one library call per step: Denoiser.forward + clamp + posterior sample with in-kernel noise
+            # (mg_denoiser_psample; a single kernel launch on the fp32 path)
+            gd._p_sample_bml(xin, ts[(T - 1 - i) % T], cond, None, None, True, out=xout, packed=pk)
 
         cur = x
         for i in range(args.warmup):
             step_(i, cur, bufs[i & 1])
             cur = bufs[i & 1]
-        n_layers = len(den.residual_layers)
+        single = single_launch(precision)
+        n_layers = 1 if single else len(den.residual_layers)
         Lh = _lib.lib()
         if not os.environ.get("MG_BENCH_NO_EVENTS"):
-            # HIP-event brackets around every 7th launch of the dominant kernel (7 is coprime with the 20
-            # layers, so every layer is sampled): bracketing all 800 launches costs ~4 % of the step
-            _lib.check(Lh.mg_profile_begin_sampled(args.steps * n_layers, 7))
+            # HIP-event brackets (on the launch stream, inside the timed region) around the dominant kernel: every
+            # launch of the single-launch forward; every 7th launch of the per-layer kernel (7 is coprime with the
+            # 20 layers, so every layer is sampled: bracketing all 800 launches costs ~4 % of the step)
+            _lib.check(Lh.mg_profile_begin_sampled(args.steps * n_layers, 1 if single else 7))
         sync()
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -172,11 +178,15 @@ def main():
 
         def roof(precision, k_ms, n_ev, dt):
             generic = os.environ.get("MG_DENOISER_GENERIC") is not None and precision == "fp32"
-            k_flop = (K3_FLOP_PER_FRAME if generic else LAYER_FLOP_PER_FRAME) * B * L
+            single = single_launch(precision)
+            k_flop = (FLOP_PER_FRAME if single else K3_FLOP_PER_FRAME if generic else LAYER_FLOP_PER_FRAME) * B * L
             achieved = k_flop / (k_ms * 1e-3) / 1e12
             whole = FLOP_PER_FRAME * B * L * args.steps / dt / 1e12
             if precision == "fp32":
-                name = ("conv_mfma_kernel<K=3> 256->512 + GLU gate epilogue" if generic else
+                name = ("denoiser_persist_kernel (the whole p_sample step in one launch: input projection, 20 residual "
+                        "layers, skip / output projections, clamp + posterior sample with Philox noise), "
+                        "v_mfma_f32_32x32x2_f32" if single else
+                        "conv_mfma_kernel<K=3> 256->512 + GLU gate epilogue" if generic else
                         "resblock_fused_kernel (one residual layer: cond 1x1 + k3 conv + gate + out 1x1 + res/skip), "
                         "v_mfma_f32_32x32x2_f32")
                 peak = FP32_MFMA_PEAK_TFLOPS
@@ -189,7 +199,8 @@ def main():
                          "vs_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 3)}
             r = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                  "frac": round(achieved / peak, 4),
-                 "traffic": TRAFFIC_BYTES.get(precision) if (B, L) == (B_PER_GPU, L_FRAMES) else None, "kernel_ms": round(k_ms, 4),
+                 "traffic": TRAFFIC_BYTES.get(precision) if (B, L) == (B_PER_GPU, L_FRAMES) and not single else None,
+                 "kernel_ms": round(k_ms, 4),
                  "launches_timed": n_ev, "whole_step_tflops": round(whole, 2),
                  "whole_step_frac": round(whole / peak, 4)}
             r.update(extra)

@@ -200,6 +200,26 @@ int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, const float 
                     const int64_t *t, const float *cond, const float *spk, float *out,
                     float *workspace, size_t workspace_floats, int B, int L, int mode, void *stream);
 
+/* The workspace's first use must find its 64-float counter block zeroed (allocate it zero-filled once; the kernels
+ * re-arm the counters themselves, also under hipGraph replay).
+ *
+ * p_sample (model/diffusion.py:121-129) as one call: x_0 = Denoiser.forward(x_t, t, cond, spk); clamp to [-1, 1] when
+ * clip; x_prev = coef1[t] x_0 + coef2[t] x_t + (t > 0) exp(0.5 logvar[t]) * noise  (q_posterior + q_posterior_sample,
+ * :104-119).  coef1 / coef2 / logvar: the posterior_mean_coef1 / posterior_mean_coef2 / posterior_log_variance_clipped
+ * buffers [n_steps].  noise [B, M, L], or NULL: N(0,1) from Philox4x32-10 keyed by `seed` with a per-call counter kept
+ * in the workspace (fresh noise on every call and on every replay of a captured graph).  x_prev [B, M, L] must not
+ * alias x_t; x0_out (optional) receives the pre-clamp x_0.  On the fp32 inference path this is ONE kernel launch. */
+int mg_denoiser_psample(const mg_denoiser_dims *d, const float *packed, const float *x_t, const int64_t *t,
+                        const float *cond, const float *spk, const float *coef1, const float *coef2,
+                        const float *logvar, int n_steps, const float *noise, unsigned long long seed, int clip,
+                        float *x_prev, float *x0_out, float *workspace, size_t workspace_floats, int B, int L, int mode,
+                        void *stream);
+/* Copies the single-launch forward's counter words {ticket, error, launches, workgroups done} of a (B, L, no-save)
+ * workspace to host_out4 and synchronises the stream: error != 0 means a neighbour hand-off timed out (the launch
+ * drained instead of hanging; its output is invalid). */
+int mg_denoiser_persist_status(const mg_denoiser_dims *d, const float *workspace, int B, int L, unsigned *host_out4,
+                               void *stream);
+
 /* Backward of Denoiser.forward (what torch.autograd does for the reference).  `workspace` is the
  * forward's workspace of a save_for_backward call on the same inputs; `bwd_workspace` has
  * mg_denoiser_bwd_workspace_floats() floats.  g_out [B, M, L] is dL/d(out).

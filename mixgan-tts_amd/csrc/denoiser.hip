@@ -12,6 +12,8 @@
 #include "resblock_fused.h"
 #include "resblock_split.h"
 #include "pointwise_fused.h"
+#include "denoiser_persist.h"
+#include <atomic>
 #include <cstdlib>
 
 // ------------------------------------------------------------------------------------------ epilogues
@@ -445,9 +447,92 @@ extern "C" int mg_resblock_fwd(const float *x, const float *cond, const float *w
 }
 
 // ------------------------------------------------------------------------------------------ forward
+// the clamp + posterior sample of p_sample (model/diffusion.py:113-129), fused behind the forward when given
+struct PostSample {
+    const float *coef1, *coef2, *logvar;   // [n_steps] posterior_mean_coef1/2, posterior_log_variance_clipped
+    const float *noise;                    // [B, M, L] or NULL (in-kernel Philox)
+    unsigned long long seed;
+    float *x0_out;                         // optional pre-clamp x_0
+    int n_steps, clip;
+};
+
+static std::atomic<unsigned> g_persist_epoch{0};
+
+static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, const float *x_t, const int64_t *t,
+                            const float *cond, const float *spk, float *out, float *ws, size_t ws_floats, int B,
+                            int L, int mode, const PostSample *post, void *stream);
+
 extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, const float *x_t, const int64_t *t,
                                const float *cond, const float *spk, float *out, float *ws, size_t ws_floats, int B,
                                int L, int mode, void *stream)
+{
+    return denoiser_forward(d, packed, x_t, t, cond, spk, out, ws, ws_floats, B, L, mode, nullptr, stream);
+}
+
+extern "C" int mg_denoiser_psample(const mg_denoiser_dims *d, const float *packed, const float *x_t, const int64_t *t,
+                                   const float *cond, const float *spk, const float *coef1, const float *coef2,
+                                   const float *logvar, int n_steps, const float *noise, unsigned long long seed, int clip,
+                                   float *x_prev, float *x0_out, float *ws, size_t ws_floats, int B, int L, int mode,
+                                   void *stream)
+{
+    if (!coef1 || !coef2 || !logvar || n_steps <= 0 || !x_prev) return MG_ERR_ARG;
+    if (mode & MG_FWD_SAVE) return MG_ERR_ARG;
+    if (x_prev == x_t) return MG_ERR_ARG;   // the posterior reads x_t after other tiles have written x_prev
+    const PostSample ps{coef1, coef2, logvar, noise, seed, x0_out, n_steps, clip};
+    return denoiser_forward(d, packed, x_t, t, cond, spk, x_prev, ws, ws_floats, B, L, mode, &ps, stream);
+}
+
+extern "C" int mg_denoiser_persist_status(const mg_denoiser_dims *d, const float *ws, int B, int L, unsigned *host_out4,
+                                          void *stream)
+{
+    if (den_check(d) != MG_OK || !ws || !host_out4 || B <= 0 || L <= 0) return MG_ERR_ARG;
+    const DenWs w = den_ws(d, B, L, 0);
+    hipError_t e = hipMemcpyAsync(host_out4, ws + w.sync, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    return e == hipSuccess ? MG_OK : (int)e;
+}
+
+// Philox normal fill + posterior for the launch-per-layer path (same generator and element indexing as the fused tail)
+__global__ void psample_tail_kernel(const float *__restrict__ x0, const float *__restrict__ x_t, const int64_t *__restrict__ t,
+                                    const float *__restrict__ coef1, const float *__restrict__ coef2,
+                                    const float *__restrict__ logvar, const float *__restrict__ noise,
+                                    unsigned long long seed, const unsigned *__restrict__ launch_ctr, float *__restrict__ out,
+                                    float *__restrict__ x0_out, int n_steps, int clip, size_t per_sample, size_t n)
+{
+    const unsigned long long off = launch_ctr ? launch_ctr[0] : 0ull;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = e / per_sample;
+        long tb = (long)t[b];
+        tb = tb < 0 ? 0 : (tb >= n_steps ? n_steps - 1 : tb);
+        const float sg = tb == 0 ? 0.f : __expf(0.5f * logvar[tb]);
+        float v = x0[e];
+        if (x0_out && x0_out != x0) x0_out[e] = v;
+        if (clip) v = fminf(fmaxf(v, -1.f), 1.f);
+        const float nz = noise ? noise[e] : dp_normal(seed, off, e);
+        out[e] = fmaf(sg, nz, fmaf(coef1[tb], v, coef2[tb] * x_t[e]));
+    }
+}
+
+__global__ void bump_counter_kernel(unsigned *ctr) { ctr[0] += 1u; }
+
+static int psample_tail(const PostSample &ps, const float *x0, const float *x_t, const int64_t *t, float *out,
+                        unsigned *sync, int B, int M, int L, hipStream_t st)
+{
+    const size_t per = (size_t)M * L, n = per * B;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(psample_tail_kernel, dim3(blocks), dim3(256), 0, st, x0, x_t, t, ps.coef1, ps.coef2, ps.logvar,
+                       ps.noise, ps.seed, sync + 2, out, ps.x0_out, ps.n_steps, ps.clip, per, n);
+    MG_LAUNCH_CHECK();
+    if (!ps.noise) {   // the launch counter is the Philox offset: one fresh stream per call
+        hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(1), 0, st, sync + 2);
+        MG_LAUNCH_CHECK();
+    }
+    return MG_OK;
+}
+
+static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, const float *x_t, const int64_t *t,
+                            const float *cond, const float *spk, float *out, float *ws, size_t ws_floats, int B,
+                            int L, int mode, const PostSample *post, void *stream)
 {
     const int save = mode & MG_FWD_SAVE;
     const int split = mode & MG_FWD_SPLIT;
@@ -477,6 +562,64 @@ extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, c
 
     static const bool force_generic = std::getenv("MG_DENOISER_GENERIC") != nullptr;
     const bool fused = !force_generic && C == RB_C && H == RB_C;
+    // ---- single-launch forward (denoiser_persist.h): inference in exact fp32; an utterance's chain of 32-frame tiles
+    // must fit in a quarter of the chip's 512 slots (forward progress with another process on the GPU), and the tag
+    // scheme needs >= 3 layers.  MG_DENOISER_PERSIST=0 keeps the launch-per-layer kernels.
+    const char *pe = std::getenv("MG_DENOISER_PERSIST");   // read per call: tests pin each path
+    const bool no_persist = pe && pe[0] == '0';
+    const int tiles_per_b = mg_cdiv(L, DP_NT);
+    if (fused && !no_persist && !save && !split && M <= 96 && NL >= 3 && tiles_per_b <= 128) {
+        PersistArgs a;
+        a.x_t = x_t;
+        a.cond = cond;
+        a.in_w = packed + o.in_w;
+        a.in_b = packed + o.in_b;
+        a.layers = lay0;
+        a.layer_stride = o.layer_stride;
+        a.l_wc = o.l_wc;
+        a.l_w3 = o.l_w3;
+        a.l_wo = o.l_wo;
+        a.l_bc = o.l_bc;
+        a.l_b3 = o.l_b3;
+        a.l_bo = o.l_bo;
+        a.skip_w = packed + o.skip_w;
+        a.skip_b = packed + o.skip_b;
+        a.out_w = packed + o.out_w;
+        a.out_b = packed + o.out_b;
+        a.hvec = ws + w.hvec;
+        a.dvec = ws + w.dvec;
+        a.out = out;
+        a.t = t;
+        a.coef1 = post ? post->coef1 : nullptr;
+        a.coef2 = post ? post->coef2 : nullptr;
+        a.logvar = post ? post->logvar : nullptr;
+        a.noise = post ? post->noise : nullptr;
+        a.seed = post ? post->seed : 0ull;
+        a.x0_out = post ? post->x0_out : nullptr;
+        a.gran = reinterpret_cast<dp_u64 *>(ws + w.gran);
+        a.sync = reinterpret_cast<unsigned *>(ws + w.sync);
+        a.epoch_base = g_persist_epoch.fetch_add((unsigned)NL + 1u);
+        a.B = B;
+        a.L = L;
+        a.M = M;
+        a.NL = NL;
+        a.tiles_per_b = tiles_per_b;
+        a.post = post ? 1 : 0;
+        a.clip = post ? post->clip : 0;
+        a.n_steps = post ? post->n_steps : 1;
+        a.rsNL = 1.0f / sqrtf((float)NL);
+        const bool vec4 = (L % 4 == 0) && (((uintptr_t)cond & 15) == 0);
+        dim3 grid((unsigned)(tiles_per_b * B));
+        prof_mark(st, 0);
+        if (vec4) hipLaunchKernelGGL(denoiser_persist_kernel<true>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(denoiser_persist_kernel<false>, grid, dim3(256), 0, st, a);
+        prof_mark(st, 1);
+        MG_LAUNCH_CHECK();
+        return MG_OK;
+    }
+    // launch-per-layer path: x_0 first (into `out`), the posterior as one more elementwise launch at the end
+    float *const final_out = out;
+    if (post && post->x0_out) out = post->x0_out;   // otherwise x_0 is produced in `out` and overwritten in place
     // input projection + ReLU (model/modules.py:430-431; the second relu is idempotent)
     if (fused && M <= 96) {
         HeadArgs ha{x_t, packed + o.in_w, packed + o.in_b, ws + w.x0, M, L, mg_cdiv(L, RB_NT)};
@@ -586,7 +729,7 @@ extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, c
                     save ? ws + w.y : nullptr, out, 1.0f / sqrtf((float)NL), M, L, mg_cdiv(L, RB_NT)};
         hipLaunchKernelGGL(denoiser_tail_kernel, dim3((unsigned)(ta.tiles_per_b * B)), dim3(512), 0, st, ta);
         MG_LAUNCH_CHECK();
-        return MG_OK;
+        return post ? psample_tail(*post, out, x_t, t, final_out, reinterpret_cast<unsigned *>(ws + w.sync), B, M, L, st) : MG_OK;
     }
     {
         ConvShape s{B, C, L, L, 1, 1, 0, C, 0, 0};
@@ -598,5 +741,5 @@ extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, c
         EpiBiasAct::Params ep{out, packed + o.out_b, nullptr, 1.f, M, MG_ACT_NONE, 0, 0, nullptr, 0.f};
         MG_TRY(conv_launch<EpiBiasAct>(s, ws + w.y, nullptr, packed + o.out_w, ep, st));
     }
-    return MG_OK;
+    return post ? psample_tail(*post, out, x_t, t, final_out, reinterpret_cast<unsigned *>(ws + w.sync), B, M, L, st) : MG_OK;
 }

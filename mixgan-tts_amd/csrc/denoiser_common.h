@@ -115,7 +115,13 @@ static inline int den_check(const mg_denoiser_dims *d)
 struct DenWs {
     size_t emb, h1pre, h1, s, dvec, hvec, x, skip, y, x0, h, g, sig, tnh, conds, total;
     size_t act_stride;  // per-layer stride of h/g/sig/tnh (0 when not saving)
+    // single-launch forward (denoiser_persist.h): 64 floats of counters (must be ZERO when the workspace is first used;
+    // the kernel re-arms them itself) and the halo hand-off granules [2][tiles][2][C] x 8 bytes
+    size_t sync, gran;
 };
+
+// 32-frame tiles of the single-launch forward
+static inline size_t den_persist_tiles(int B, int L) { return (size_t)B * ((L + 31) / 32); }
 
 static inline DenWs den_ws(const mg_denoiser_dims *d, int B, int L, int save)
 {
@@ -145,6 +151,8 @@ static inline DenWs den_ws(const mg_denoiser_dims *d, int B, int L, int save)
     w.sig = save ? take(act * nact) : 0;
     w.tnh = save ? take(act * nact) : 0;
     w.conds = take(act);  // frame-major bf16 hi/lo planes of the conditioner (split-precision path)
+    w.sync = take(64);
+    w.gran = take(2 * den_persist_tiles(B, L) * 2 * C * 2);
     w.total = p;
     return w;
 }

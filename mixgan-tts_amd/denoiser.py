@@ -93,7 +93,8 @@ class Denoiser(nn.Module):
         """A private workspace (not cached): for owners that keep raw pointers into it across calls, e.g. a captured
         hipGraph, which must hold the tensor for as long as the graph lives."""
         n = _lib.lib().mg_denoiser_workspace_floats(ctypes.byref(self._dims), B, L, int(save))
-        return torch.empty(n, device=dev, dtype=torch.float32)
+        # zero-filled once: the single-launch forward keeps its ticket / launch counters in here and re-arms them itself
+        return torch.zeros(n, device=dev, dtype=torch.float32)
 
     def _workspace(self, B, L, save, dev):
         """Cached per shape.  The cache only saves re-allocation: whoever needs a workspace to outlive the call (a
@@ -134,6 +135,37 @@ class Denoiser(nn.Module):
                                          fptr(cond), fptr(spk, not self.multi_speaker), fptr(out), fptr(ws),
                                          ws.numel(), B, L, mode, stream_ptr()))
         return out
+
+    def p_sample(self, x_t, t, cond, spk, coef1, coef2, logvar, noise=None, clip=True, out=None, x0_out=None,
+                 packed=None, ws=None):
+        """One reverse step (model/diffusion.py:121-129) as one library call: x_0 = forward(x_t); clamp; posterior mean
+        + sigma * noise.  x_t [B,M,L], cond [B,H,L]; coef1 / coef2 / logvar: the diffusion's posterior_mean_coef1 / 2 and
+        posterior_log_variance_clipped buffers.  noise None = drawn in the kernel (Philox keyed by a seed taken once
+        from torch's generator, counter kept on the device: fresh on every call and every graph replay).
+        Returns x_{t-1} [B,M,L] (a new tensor or `out`, never x_t itself)."""
+        B, M, L = x_t.shape
+        if packed is None:
+            packed = self.packed_weights()
+        if ws is None:
+            ws = self._workspace(B, L, False, x_t.device)
+        if out is None:
+            out = torch.empty_like(x_t)
+        if getattr(self, "_rng_seed", None) is None:
+            self._rng_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        mode = 2 if self.precision == "bf16x3" else 0
+        check(_lib.lib().mg_denoiser_psample(
+            ctypes.byref(self._dims), fptr(packed), fptr(x_t), iptr(t, torch.int64), fptr(cond),
+            fptr(spk, not self.multi_speaker), fptr(coef1), fptr(coef2), fptr(logvar), coef1.numel(), fptr(noise, True),
+            self._rng_seed, int(bool(clip)), fptr(out), fptr(x0_out, True), fptr(ws), ws.numel(), B, L, mode, stream_ptr()))
+        return out
+
+    def persist_status(self, B, L, ws=None):
+        """{ticket, error, launches, done} of the single-launch forward's counters for this shape (synchronises);
+        error != 0: a neighbour hand-off timed out and that launch's output is invalid."""
+        ws = self._workspace(B, L, False, next(self.parameters()).device) if ws is None else ws
+        host = (ctypes.c_uint * 4)()
+        check(_lib.lib().mg_denoiser_persist_status(ctypes.byref(self._dims), fptr(ws), B, L, host, stream_ptr()))
+        return {"ticket": host[0], "error": host[1], "launches": host[2], "done": host[3]}
 
     def forward(self, mel, diffusion_step, conditioner, speaker_emb, mask=None):
         """mel [B,1,M,T], diffusion_step [B], conditioner [B,H,T], speaker_emb [B,H]|None -> [B,1,M,T]."""

@@ -112,10 +112,15 @@ class GaussianDiffusion(nn.Module):
     def p_sample(self, x_t, t, cond, spk_emb, clip_denoised=True, repeat_noise=False):
         """model/diffusion.py:121-129; x_t [B,1,M,L], cond [B,H,L]."""
         x = self._bml(x_t)
-        x0 = self.denoise_fn.run(x, t.contiguous(), cond.contiguous(), spk_emb)
         B, M, L = x.shape
-        noise = self._bml(self._randn((B, 1, M, L), x.device))
-        return ops.posterior_sample(x0, x, t.contiguous(), noise, None, self._buf(), clip=clip_denoised)[:, None]
+        noise = self._bml(self._randn((B, 1, M, L), x.device)) if self.noise_fn is not None else None
+        return self._p_sample_bml(x, t.contiguous(), cond.contiguous(), spk_emb, noise, clip_denoised)[:, None]
+
+    def _p_sample_bml(self, x, t, cond, spk, noise, clip=True, out=None, packed=None, ws=None):
+        """Denoiser.forward + clamp + posterior sample on [B,M,L] tensors as ONE library call (one kernel launch on the
+        fp32 inference path).  noise None: N(0,1) drawn inside the kernel."""
+        return self.denoise_fn.p_sample(x, t, cond, spk, self.posterior_mean_coef1, self.posterior_mean_coef2,
+                                        self.posterior_log_variance_clipped, noise, clip, out, None, packed, ws)
 
     @torch.no_grad()
     def sampling(self, noise=None, keep_trace=True, use_graph=False, _final_keep=None):
@@ -136,12 +141,10 @@ class GaussianDiffusion(nn.Module):
         packed = den.packed_weights()
         x = self._bml(self._randn((B, 1, M, L), dev) if noise is None else noise)
         xs = [x] if keep_trace else None
-        x0 = torch.empty_like(x)
         for i in reversed(range(T)):
             t = torch.full((B,), i, device=dev, dtype=torch.long)
-            den.run(x, t, cond, self.spk_emb, out=x0, packed=packed)
-            nz = self._bml(self._randn((B, 1, M, L), dev))
-            x = ops.posterior_sample(x0, x, t, nz, None, buf, clip=True)
+            nz = self._bml(self._randn((B, 1, M, L), dev)) if self.noise_fn is not None else None
+            x = self._p_sample_bml(x, t, cond, self.spk_emb, nz, True, packed=packed)
             if keep_trace:
                 xs.append(x)
         outs = xs if keep_trace else [x]
@@ -161,7 +164,6 @@ class GaussianDiffusion(nn.Module):
         if g is None or g["key"] != key:
             buf = self._buf()
             st = {"key": key, "x": [torch.empty_like(x_start), torch.empty_like(x_start)],
-                  "x0": torch.empty_like(x_start), "noise": torch.empty_like(x_start),
                   "cond": torch.empty_like(cond), "spk": None if spk is None else torch.empty_like(spk),
                   "ts": [torch.full((B,), i, device=dev, dtype=torch.long) for i in range(T)],
                   # the graph bakes in raw pointers: it owns its workspace and holds the packed weights it captured
@@ -174,10 +176,8 @@ class GaussianDiffusion(nn.Module):
             def loop():
                 cur = 0
                 for i in reversed(range(T)):
-                    den.run(st["x"][cur], st["ts"][i], st["cond"], st["spk"], out=st["x0"], packed=packed, ws=st["ws"])
-                    st["noise"].normal_()
-                    ops.posterior_sample(st["x0"], st["x"][cur], st["ts"][i], st["noise"], None, buf, clip=True,
-                                         out=st["x"][cur ^ 1])
+                    self._p_sample_bml(st["x"][cur], st["ts"][i], st["cond"], st["spk"], None, True,
+                                       out=st["x"][cur ^ 1], packed=packed, ws=st["ws"])
                     cur ^= 1
                 return cur
 

@@ -148,6 +148,7 @@ def test_fused_layer_tile_widths(mg, manifest, tmp_path, monkeypatch, tile):
     chip).  Each one, forced through MG_RB_TILE, against the reference fixture (forward) and against the oracle
     at ragged sizes, with and without the activation saves of the training forward."""
     monkeypatch.setenv("MG_RB_TILE", str(tile))
+    monkeypatch.setenv("MG_DENOISER_PERSIST", "0")     # the launch-per-layer kernels (inference defaults to the single-launch one)
     g = golden("denoiser_ms1")
     _, pre, mc, _ = hot_path_configs(multi_speaker=True, stats_dir=str(tmp_path))
     den = mg.Denoiser(pre, mc)
@@ -184,6 +185,7 @@ def test_fused_layer_tile_widths(mg, manifest, tmp_path, monkeypatch, tile):
 def test_fused_layer_narrow_tiles_equal_wide_bitwise(mg, manifest, tmp_path, monkeypatch):
     """Every output element sees the same k order whatever the tile width, so B=8 x L=1000 (the per-GPU training
     shard: 256 workgroups of 32 frames) must reproduce the 64-frame tiling bit for bit."""
+    monkeypatch.setenv("MG_DENOISER_PERSIST", "0")
     _, pre, mc, _ = hot_path_configs(stats_dir=str(tmp_path))
     den = mg.Denoiser(pre, mc)
     load_seeded(den, manifest, "denoiser_ms0", 77)

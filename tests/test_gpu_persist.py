@@ -1,0 +1,155 @@
+"""The single-launch Denoiser.forward / p_sample (csrc/denoiser_persist.h: 32-frame tiles resident for all layers, two
+workgroups per CU, halo columns of h handed between neighbouring workgroups inside the launch) against the oracle, against
+the launch-per-layer kernels, and against itself under conditions that expose a stale or torn hand-off: full chip
+occupancy (B=16, L=1000 = 512 workgroups), repeated launches, a second stream hammering HBM, single samples vs the
+batch (bitwise)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden, T, seeded, assert_close, hot_path_configs, write_stats, load_seeded, Tape
+from oracle import refmath as R, schedule as S
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def mg():
+    import mixgan_tts_amd as m
+    assert torch.cuda.is_available()
+    return m
+
+
+def _den(mg, manifest, tmp_path, ms=False):
+    name = "denoiser_ms%d" % int(ms)
+    _, pre, mc, _ = hot_path_configs(multi_speaker=ms, stats_dir=str(tmp_path))
+    den = mg.Denoiser(pre, mc)
+    load_seeded(den, manifest, name, 21 + int(ms))
+    W, _ = seeded(manifest, name, 21 + int(ms))
+    return den.cuda(), W
+
+
+@pytest.mark.parametrize("ms", [False, True])
+def test_single_launch_forward_vs_oracle_and_per_layer_path(mg, manifest, tmp_path, monkeypatch, ms):
+    den, W = _den(mg, manifest, tmp_path, ms)
+    gen = torch.Generator().manual_seed(11)
+    # one tile, a partial tile, tile boundaries, L % 4 != 0 (scalar staging) and == 0 (float4 staging)
+    for B, L in [(1, 1), (2, 31), (1, 32), (3, 33), (2, 129), (1, 300), (5, 257), (2, 64), (1, 1000)]:
+        x = torch.randn(B, 1, 80, L, generator=gen)
+        cond = torch.randn(B, 256, L, generator=gen)
+        spk = torch.randn(B, 256, generator=gen) if ms else None
+        t = torch.randint(0, 1000, (B,), generator=gen)
+        with torch.no_grad():
+            ref = R.denoiser_forward(W, "", x, t, cond, spk)
+            args = (x.cuda(), t.cuda(), cond.cuda(), None if spk is None else spk.cuda())
+            monkeypatch.delenv("MG_DENOISER_PERSIST", raising=False)
+            out = den(*args)
+            monkeypatch.setenv("MG_DENOISER_PERSIST", "0")
+            per_layer = den(*args)
+            monkeypatch.delenv("MG_DENOISER_PERSIST", raising=False)
+        st = den.persist_status(B, L)
+        assert st["error"] == 0 and st["ticket"] == 0 and st["done"] == 0 and st["launches"] >= 1, st
+        assert_close(out.cpu(), ref, TOL, "single launch B=%d L=%d" % (B, L))
+        assert_close(out.cpu(), per_layer.cpu(), TOL, "single launch vs per-layer kernels B=%d L=%d" % (B, L))
+
+
+def test_fused_p_sample_vs_oracle(mg, manifest, tmp_path):
+    e = golden("elementwise")
+    stats = write_stats(tmp_path, e["spec_min"], e["spec_max"])
+    gd = mg.GaussianDiffusion(*hot_path_configs("naive", 4, stats_dir=stats))
+    load_seeded(gd, manifest, "diffusion_naive_ms0", 31)
+    W, _ = seeded(manifest, "diffusion_naive_ms0", 31)
+    buf = {k: T(v) for k, v in S.diffusion_buffers(S.beta_schedule("vpsde", 4, 0.1, 40, 0.008)).items()}
+    gd = gd.cuda().eval()
+    gen = torch.Generator().manual_seed(5)
+    for B, L in [(3, 50), (2, 96), (4, 257)]:
+        x_t = torch.randn(B, 1, 80, L, generator=gen)
+        cond = torch.randn(B, 256, L, generator=gen)
+        nz = torch.randn(B, 1, 80, L, generator=gen)
+        t = torch.tensor([3, 0, 2, 1][:B])
+        for clip in (True, False):
+            ref = R.p_sample(W, buf, x_t, t, cond, None, nz, clip=clip)
+            gd.noise_fn = Tape([nz.numpy()])
+            out = gd.p_sample(x_t.cuda(), t.cuda(), cond.cuda(), None, clip_denoised=clip)
+            assert_close(out.cpu(), ref, TOL, "fused p_sample B=%d L=%d clip=%s" % (B, L, clip))
+    gd.noise_fn = None
+
+
+def test_in_kernel_noise_is_standard_normal_and_fresh(mg, manifest, tmp_path):
+    e = golden("elementwise")
+    stats = write_stats(tmp_path, e["spec_min"], e["spec_max"])
+    gd = mg.GaussianDiffusion(*hot_path_configs("naive", 4, stats_dir=stats))
+    load_seeded(gd, manifest, "diffusion_naive_ms0", 31)
+    gd = gd.cuda().eval()
+    B, L = 4, 512
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    x_t = torch.randn(B, 1, 80, L, device="cuda", generator=gen)
+    cond = torch.randn(B, 256, L, device="cuda", generator=gen)
+    t = torch.tensor([3, 2, 1, 0], device="cuda")
+    zero = torch.zeros(B, 1, 80, L)
+    gd.noise_fn = Tape([zero.numpy()])
+    mean = gd.p_sample(x_t, t, cond, None)                  # sigma * 0: the posterior mean alone
+    gd.noise_fn = None
+    a = gd.p_sample(x_t, t, cond, None)
+    b = gd.p_sample(x_t, t, cond, None)
+    sig = torch.exp(0.5 * gd.posterior_log_variance_clipped[t]).view(B, 1, 1, 1)
+    za, zb = ((a - mean) / sig)[:3], ((b - mean) / sig)[:3]  # rows with t > 0
+    assert torch.equal(a[3], mean[3]) and torch.equal(b[3], mean[3])        # t == 0: no noise (model/diffusion.py:116)
+    for z in (za, zb):
+        n = z.numel()
+        assert abs(z.mean().item()) < 5.0 / n ** 0.5 and abs(z.var().item() - 1.0) < 0.02
+        assert abs((z ** 3).mean().item()) < 0.05 and abs((z ** 4).mean().item() - 3.0) < 0.1
+        assert abs(torch.corrcoef(torch.stack([z.flatten()[:-1], z.flatten()[1:]]))[0, 1].item()) < 0.01
+    assert abs(torch.corrcoef(torch.stack([za.flatten(), zb.flatten()]))[0, 1].item()) < 0.01   # a fresh stream per call
+
+
+def test_full_occupancy_handoffs_are_never_stale(mg, manifest, tmp_path, monkeypatch):
+    """B=16, L=1000: 512 workgroups, two per CU, every tile waiting on both neighbours in every layer.  The output must be
+    bit-identical run after run, with or without a second stream saturating HBM beside it, and identical to what each
+    utterance gives alone (other placement, other neighbours in flight); and it must match the per-layer kernels."""
+    den, W = _den(mg, manifest, tmp_path)
+    gen = torch.Generator(device="cuda").manual_seed(16)
+    B, L = 16, 1000
+    x = torch.randn(B, 1, 80, L, device="cuda", generator=gen)
+    cond = torch.randn(B, 256, L, device="cuda", generator=gen)
+    t = torch.randint(0, 1000, (B,), device="cuda", generator=gen)
+    with torch.no_grad():
+        first = den(x, t, cond, None).clone()
+        for _ in range(5):
+            assert torch.equal(den(x, t, cond, None), first)
+        side = torch.cuda.Stream()
+        big = torch.empty(1 << 28, device="cuda")                      # 1 GiB
+        with torch.cuda.stream(side):
+            for _ in range(40):
+                big.add_(1.0)
+        for _ in range(10):
+            assert torch.equal(den(x, t, cond, None), first)
+        side.synchronize()
+        for bi in (0, 7, 15):
+            one = den(x[bi:bi + 1], t[bi:bi + 1], cond[bi:bi + 1], None)
+            assert torch.equal(one[0], first[bi])
+        monkeypatch.setenv("MG_DENOISER_PERSIST", "0")
+        per_layer = den(x, t, cond, None)
+    assert den.persist_status(B, L)["error"] == 0
+    assert_close(first.cpu(), per_layer.cpu(), TOL, "single launch vs per-layer kernels at B=16 L=1000")
+    with torch.no_grad():
+        ref = R.denoiser_forward(W, "", x[:1].cpu(), t[:1].cpu(), cond[:1].cpu(), None)
+    assert_close(first[:1].cpu(), ref, TOL, "vs oracle")
+
+
+def test_more_tiles_than_slots_and_long_utterances(mg, manifest, tmp_path):
+    """B=40, L=1000 = 1280 workgroups on 512 slots (later tiles start as earlier utterances finish), and L=4000 (125-tile
+    chains): finite, deterministic, equal to each sample alone."""
+    den, _ = _den(mg, manifest, tmp_path)
+    gen = torch.Generator(device="cuda").manual_seed(40)
+    for B, L in [(40, 1000), (6, 4000)]:
+        x = torch.randn(B, 1, 80, L, device="cuda", generator=gen)
+        cond = torch.randn(B, 256, L, device="cuda", generator=gen)
+        t = torch.randint(0, 1000, (B,), device="cuda", generator=gen)
+        with torch.no_grad():
+            a = den(x, t, cond, None).clone()
+            b = den(x, t, cond, None)
+            one = den(x[B - 1:], t[B - 1:], cond[B - 1:], None)
+        assert den.persist_status(B, L)["error"] == 0
+        assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(one[0], a[B - 1])
