@@ -457,6 +457,10 @@ struct PostSample {
 };
 
 static std::atomic<unsigned> g_persist_epoch{0};
+// tools only (tools/persist_timeline.py): when set, launches with float4 staging run the TIMING instantiation, which
+// writes lane 0's cycle stamps [tiles][NL + 2][12] here.  Not declared in the public header.
+static unsigned long long *g_persist_dbg = nullptr;
+extern "C" void mg_debug_persist_stamps(unsigned long long *device_buffer) { g_persist_dbg = device_buffer; }
 
 static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, const float *x_t, const int64_t *t,
                             const float *cond, const float *spk, float *out, float *ws, size_t ws_floats, int B,
@@ -567,8 +571,16 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
     // scheme needs >= 3 layers.  MG_DENOISER_PERSIST=0 keeps the launch-per-layer kernels.
     const char *pe = std::getenv("MG_DENOISER_PERSIST");   // read per call: tests pin each path
     const bool no_persist = pe && pe[0] == '0';
-    const int tiles_per_b = mg_cdiv(L, DP_NT);
-    if (fused && !no_persist && !save && !split && M <= 96 && NL >= 3 && tiles_per_b <= 128) {
+    // tile width: 64 frames (8 waves, one workgroup per CU, weights streamed once per 64 frames) when that still gives
+    // more than 128 workgroups, else 32 frames (4 waves, two per CU: twice the workgroups for small launches)
+    int nt = (long)mg_cdiv(L, 64) * B > 128 ? 64 : 32;
+    if (const char *ne = std::getenv("MG_PERSIST_NT")) {   // tests pin each width
+        const int f = std::atoi(ne);
+        if (f == 32 || f == 64) nt = f;
+    }
+    const int tiles_per_b = mg_cdiv(L, nt);
+    const int chain_cap = nt == 64 ? 64 : 128;   // a quarter of the 256 / 512 slots
+    if (fused && !no_persist && !save && !split && M <= 96 && NL >= 3 && tiles_per_b <= chain_cap) {
         PersistArgs a;
         a.x_t = x_t;
         a.cond = cond;
@@ -608,11 +620,25 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
         a.clip = post ? post->clip : 0;
         a.n_steps = post ? post->n_steps : 1;
         a.rsNL = 1.0f / sqrtf((float)NL);
+        a.dbg = g_persist_dbg;
+        {
+            const char *fe = std::getenv("MG_PERSIST_FLAGS");
+            a.flags = fe ? std::atoi(fe) : DP_F_ROLES;
+        }
         const bool vec4 = (L % 4 == 0) && (((uintptr_t)cond & 15) == 0);
         dim3 grid((unsigned)(tiles_per_b * B));
         prof_mark(st, 0);
-        if (vec4) hipLaunchKernelGGL(denoiser_persist_kernel<true>, grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(denoiser_persist_kernel<false>, grid, dim3(256), 0, st, a);
+#define MG_DP_LAUNCH(NT, V, T) hipLaunchKernelGGL((denoiser_persist_kernel<NT, V, T>), grid, dim3(NT * 8), 0, st, a)
+        if (nt == 64) {
+            if (g_persist_dbg && vec4) MG_DP_LAUNCH(64, true, true);
+            else if (vec4) MG_DP_LAUNCH(64, true, false);
+            else MG_DP_LAUNCH(64, false, false);
+        } else {
+            if (g_persist_dbg && vec4) MG_DP_LAUNCH(32, true, true);
+            else if (vec4) MG_DP_LAUNCH(32, true, false);
+            else MG_DP_LAUNCH(32, false, false);
+        }
+#undef MG_DP_LAUNCH
         prof_mark(st, 1);
         MG_LAUNCH_CHECK();
         return MG_OK;

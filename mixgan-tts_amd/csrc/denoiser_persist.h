@@ -2,37 +2,34 @@
 // layers (model/blocks.py:1157-1176), skip / output projections and (optionally) the clamp + posterior sample of
 // p_sample (model/diffusion.py:113-129) run in a single persistent kernel.
 //
-// Why: the one-launch-per-layer kernel (resblock_fused.h) runs one 8-wave workgroup per CU, so nothing overlaps its
-// prologue (cond tile staging), its three phase hand-overs and its epilogue with matrix work: 163 us per layer against
-// a 123 us MFMA floor, and 5.3 % of its MFMAs are the recomputed halo columns.  Here
-//   * a workgroup is 4 waves (one per SIMD) and owns 32 frames of one utterance for ALL layers; two workgroups share a
-//     CU (2 x 78 KB of LDS, 256 VGPRs each), so while one is between GEMMs the other keeps the matrix pipes busy;
+// Why: the one-launch-per-layer kernel (resblock_fused.h) re-stages the conditioner tile, reads and writes x / skip and
+// recomputes the halo columns of h (5.3 % of its MFMAs) in every layer, and nothing overlaps its prologue and epilogue:
+// 163 us per layer against a 123 us MFMA floor.  Here a workgroup owns NT frames of one utterance for ALL layers:
 //   * the conditioner tile is staged ONCE (it is the same for every layer) and stays in LDS;
-//   * the residual stream x and the running skip sum never leave registers: wave w owns channels 64w..64w+63 of both
-//     (they are the accumulators of GEMM 3, initialised in place), so a layer touches HBM/L2 only for its weights;
-//   * the k=3 convolution's halo is not recomputed: after GEMM 1 each workgroup hands the two edge columns of h to
-//     its neighbours (tagged 8-byte granules, write-through stores; cdna_hip_programming.md section 6 Guideline 16,
-//     form R2: the data is the flag) and runs the centre tap of GEMM 2 while they travel.  Per layer a workgroup
-//     executes exactly the algorithmic 2304 MFMAs per wave (no halo MFMAs).
-//
-// LDS per workgroup (73,728 B):
-//   condT [256][36]             col j <-> frame l0+j     (16-byte aligned rows for float4 staging); lives all layers
-//   hT    [256][36]             col j <-> frame l0-1+j   h of the current layer incl. the two halo columns;
-//                               overwritten in place by g = sigmoid * tanh (col j <-> frame l0+j) once GEMM 2 has read it
-// Forward progress: tiles are handed out by an atomic ticket in START order, so a workgroup only ever waits for
-// workgroups that have started or will start as soon as a slot frees; an utterance's tiles are consecutive tickets, and
-// the launcher uses this kernel only when an utterance's chain fits in a quarter of the chip's slots.  Every spin is bounded
-// (a timeout sets an error word and lets the kernel drain).
+//   * the residual stream x and the running skip sum never leave registers: each wave owns a fixed set of channels of
+//     both (they are the accumulators of GEMM 3, initialised in place), so a layer touches HBM / L2 only for its weights;
+//   * the k=3 convolution's halo is not recomputed: after GEMM 1 each workgroup hands the two edge columns of h to its
+//     neighbours (tagged 8-byte granules, write-through stores: cdna_hip_programming.md section 6 Guideline 16, form
+//     R2, the data is the flag) and runs the centre tap of GEMM 2 while they travel.  A workgroup executes exactly the
+//     algorithmic MFMAs (no halo MFMAs).
+// Two tile widths (same code, template parameter NT):
+//   NT = 64: 8 waves, wave w owns channels 32w..32w+31 x 64 frames; one workgroup per CU (139 KB of LDS); the weight
+//            stream is read once per 64 frames.  Used when it fills the chip (B x ceil(L/64) > 128 workgroups).
+//   NT = 32: 4 waves, wave w owns channels 64w..64w+63 x 32 frames; two workgroups per CU (2 x 74 KB); twice the
+//            workgroups for small batches / single utterances, at twice the weight stream per frame.
+// LDS: condT [256][NT+4]  col j <-> frame l0+j     (16-byte aligned rows for float4 staging); lives all layers
+//      hT    [256][NT+4]  col j <-> frame l0-1+j   h of the current layer incl. the two halo columns; overwritten in
+//                         place by g = sigmoid * tanh (col j <-> frame l0+j) once GEMM 2 has read it
+// Forward progress: tiles are handed out by atomic tickets in START order, so a workgroup only ever waits for workgroups
+// that have started or will start as soon as a slot frees; an utterance's tiles are consecutive tickets, and the launcher
+// uses this kernel only when an utterance's chain fits in a quarter of the chip's slots.  Every spin is bounded (a
+// timeout sets an error word and lets the kernel drain).
 #pragma once
 #include "common.h"
 #include "resblock_fused.h"
 
-#define DP_NT 32
-#define DP_RSC 36
-#define DP_RSH 36
-#define DP_COND_FLOATS (RB_C * DP_RSC)
-#define DP_LDS_FLOATS (DP_COND_FLOATS + RB_C * DP_RSH)
 #define DP_SPIN_LIMIT (1u << 21)   // x ~2 us per poll: seconds, then the error word is set and the kernel drains
+#define DP_F_ROLES 1               // NT = 32: two ticket queues by hardware wave slot (see the kernel)
 
 typedef unsigned long long dp_u64;
 typedef __attribute__((address_space(1))) dp_u64 dp_gu64;
@@ -54,10 +51,12 @@ struct PersistArgs {
     unsigned long long seed;
     float *x0_out;                        // optional [B, M, L]: the pre-clamp x_0 when post != 0
     dp_u64 *gran;                         // [2 parity][tiles][2 sides][256] {tag << 32 | float bits}
-    unsigned *sync;                       // [0] ticket, [1] error (sticky), [2] launches completed, [3] workgroups done;
-                                          // zero once at allocation: the last workgroup out re-arms [0] and [3]
+    unsigned *sync;                       // [0] / [16] tickets, [1] error (sticky), [2] launches completed, [3] workgroups done;
+                                          // zero once at allocation: the last workgroup out re-arms [0], [16] and [3]
     unsigned epoch_base;
+    unsigned long long *dbg;              // TIMING instantiation only: [tiles][NL + 2][12] cycle stamps of lane 0
     int B, L, M, NL, tiles_per_b, post, clip, n_steps;
+    int flags;                            // DP_F_*
     float rsNL;
 };
 
@@ -83,48 +82,60 @@ struct DpIterOuter {   // k=3 conv, taps 0 and 2
     static __device__ __forceinline__ int tap(int it) { return (it & 1) * 2; }
 };
 
-// k loop of one GEMM phase for NMB 32-row blocks x one 32-column block.  Same register pipeline as rb_mfma_loop
-// (resblock_fused.h): weight float4s two k-groups ahead in a ring of 4, LDS B fragments one k-group ahead, prefetches
-// pinned at the top of each k-group with sched_barrier; the iteration order over (chunk, tap) comes from IT.
+// k loop of one GEMM phase for NMB 32-row blocks x NNB 32-column blocks.  Register pipeline as in rb_mfma_loop
+// (resblock_fused.h): weight float4s DIST k-groups ahead in a ring of 4, LDS B fragments one k-group ahead; the
+// prefetches are pinned at the TOP of each k-group with sched_barrier (left alone, hipcc sinks them to the end of the
+// group: one k-group of latency cover instead of DIST) and the MFMAs keep the written order, which never puts two MFMAs
+// on one accumulator back to back.  The iteration order over (chunk, tap) comes from IT.
 //   ap[i]: packed weights of block i (+ lane); k-group q of (chunk, tap) = (chunk * KW + tap) * 4 + g sits at ap[i][q * 64]
-//   tile:  LDS tile + hh * RS + (this lane's column for tap 0)
-template <int NMB, int RS, class IT>
-__device__ __forceinline__ void dp_mfma_loop(f32x16 (&acc)[NMB], const f32x4 *const (&ap)[NMB], const float *__restrict__ tile)
+//   tile:  LDS tile + hh * RS + (this lane's column of n-block 0 for tap 0)
+template <int NMB, int NNB, int RS, class IT, int DIST = (NMB * NNB >= 4 ? 2 : 3)>
+__device__ __forceinline__ void dp_mfma_loop(f32x16 (&acc)[NMB][NNB], const f32x4 *const (&ap)[NMB], const float *__restrict__ tile)
 {
+    static_assert(DIST >= 1 && DIST <= 3, "ring of 4 slots");
     f32x4 ring[4][NMB];
-    float bb[2][4];
+    float bb[2][4][NNB];
     auto qbase = [](int it) { return (IT::chunk(it) * IT::KW + IT::tap(it)) * 4; };
     auto boff = [](int it) { return IT::chunk(it) * (32 * RS) + IT::tap(it); };
     {
         const int q0 = qbase(0);
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < DIST; ++s)
 #pragma unroll
             for (int i = 0; i < NMB; ++i) ring[s][i] = ap[i][(size_t)(q0 + s) * 64];
         const float *T0 = tile + boff(0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bb[0][e] = T0[(2 * e) * RS];
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < NNB; ++j) bb[0][e][j] = T0[(2 * e) * RS + 32 * j];
     }
-#pragma unroll 1   // keep the layer's code inside the instruction cache: two workgroups per CU run different phases
+#pragma unroll 1   // keep the layer's code inside the instruction cache
     for (int it = 0; it < IT::N; ++it) {
         const int itn = it + 1 < IT::N ? it + 1 : IT::N - 1;
         const int qc = qbase(it), qn = qbase(itn);
         const float *Tc = tile + boff(it), *Tn = tile + boff(itn);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int qa = u < 2 ? qc + u + 2 : qn + u - 2;   // two k-groups ahead
+            const int qa = u + DIST < 4 ? qc + u + DIST : qn + u + DIST - 4;   // DIST k-groups ahead
 #pragma unroll
-            for (int i = 0; i < NMB; ++i) ring[(u + 2) & 3][i] = ap[i][(size_t)qa * 64];
+            for (int i = 0; i < NMB; ++i) ring[(u + DIST) & 3][i] = ap[i][(size_t)qa * 64];
             {
                 const float *Tx = u < 3 ? Tc + ((u + 1) * 8) * RS : Tn;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bb[(u + 1) & 1][e] = Tx[(2 * e) * RS];
-            }
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                    for (int j = 0; j < NNB; ++j) bb[(u + 1) & 1][e][j] = Tx[(2 * e) * RS + 32 * j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
 #pragma unroll
                 for (int i = 0; i < NMB; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[u][i][e], bb[u & 1][e], acc[i], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NNB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[u][i][e], bb[u & 1][e][j], acc[i][j], 0, 0, 0);
+                if (NMB * NNB < 4) __builtin_amdgcn_sched_barrier(0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -159,90 +170,130 @@ __device__ __forceinline__ float dp_normal(unsigned long long seed, unsigned lon
 }
 
 #define DP_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define DP_STAMP(k) do { if (TIMING && tid == 0) a.dbg[((size_t)tile * (a.NL + 2) + stamp_row) * 12 + (k)] = clock64(); } while (0)
 
-template <bool VEC4>
-__global__ __launch_bounds__(256, 2) void denoiser_persist_kernel(PersistArgs a)
+template <int NT, bool VEC4, bool TIMING = false>
+__global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float lds[DP_LDS_FLOATS];
+    static_assert(NT == 32 || NT == 64, "tile widths: 32 (4 waves, two workgroups per CU) or 64 (8 waves, one)");
+    constexpr int NTHR = NT * 8, NW = NTHR / 64;    // threads, waves
+    constexpr int MB = 8 / NW;                      // 32-row blocks of the 256 channels per wave: 2 (NT = 32) or 1
+    constexpr int NNB = NT / 32;                    // 32-column blocks per tile
+    constexpr int RS = NT + 4;                      // LDS row stride of both tiles
+    __shared__ __attribute__((aligned(16))) float lds[2 * RB_C * RS];
     __shared__ unsigned s_tile, s_dead, s_launch;
     float *condT = lds;
-    float *hT = lds + DP_COND_FLOATS;
+    float *hT = lds + RB_C * RS;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int hh = lane >> 5, c32 = lane & 31;
     const int L = a.L;
 
+    // NT = 32: the two workgroups of a CU sit in different hardware wave slots; the matrix pipe serves the older wave
+    // first, so one of them runs ahead and the other fills its gaps.  A workgroup that waits for a neighbour which is
+    // the starved partner on ITS CU stalls both (measured: 18 % of the kernel): tiles are therefore dealt from two
+    // queues, utterances [0, B/2) to even slots and [B/2, B) to odd ones, so that a chain of neighbours shares one role
+    // and advances in step.  Speed only: any assignment of tiles to workgroups is correct.
+    const int n_tiles = a.tiles_per_b * a.B;
+    const unsigned hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID; WAVE_ID = bits 3:0
+    const int role = (NT == 32 && (a.flags & DP_F_ROLES)) ? (int)(hw_id & 1u) : 0;
     if (tid == 0) {
-        s_tile = __hip_atomic_fetch_add(a.sync, 1u, DP_RLX_AGENT);   // tickets in START order
+        const int nA = (NT == 32 && (a.flags & DP_F_ROLES)) ? (a.B / 2) * a.tiles_per_b : n_tiles;   // queue 0: tiles [0, nA)
+        const int n_mine = role == 0 ? nA : n_tiles - nA;
+        unsigned tk = __hip_atomic_fetch_add(a.sync + (role ? 16 : 0), 1u, DP_RLX_AGENT);   // tickets in START order
+        int tl;
+        if ((int)tk < n_mine) tl = (role == 0 ? 0 : nA) + (int)tk;
+        else {   // this role's queue is empty: the other one has exactly as many tiles left as such workgroups
+            tk = __hip_atomic_fetch_add(a.sync + (role ? 0 : 16), 1u, DP_RLX_AGENT);
+            tl = (role == 0 ? nA : 0) + (int)tk;
+        }
+        s_tile = (unsigned)tl;
         s_launch = __hip_atomic_load(a.sync + 2, DP_RLX_AGENT);      // advanced only after every workgroup has exited
         s_dead = 0u;
     }
     __syncthreads();
-    const int n_tiles = a.tiles_per_b * a.B;
-    const int tile = (int)(s_tile % (unsigned)n_tiles);
+    const int tile = min((int)s_tile, n_tiles - 1);
     const int b = tile / a.tiles_per_b, jt = tile - b * a.tiles_per_b;
-    const int l0 = jt * DP_NT;
+    const int l0 = jt * NT;
     const bool has_left = jt > 0, has_right = jt + 1 < a.tiles_per_b;
+    int stamp_row = 0;
+    DP_STAMP(0);
+    if (TIMING && tid == 0) {
+        a.dbg[((size_t)tile * (a.NL + 2)) * 12 + 2] = hw_id;
+        a.dbg[((size_t)tile * (a.NL + 2)) * 12 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+    }
 
     // ---------------------------------------------------------------- stage the cond tile (once) and the x_t tile
     {
         const float *cb = a.cond + (size_t)b * RB_C * L;
         if (VEC4) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {   // 256 rows x 8 float4 (frames l0 .. l0+31)
-                const int idx = tid + k * 256;
-                const int row = idx >> 3, c4 = idx & 7;
+            for (int k = 0; k < 8; ++k) {   // 256 rows x NT/4 float4 (frames l0 .. l0+NT-1)
+                const int idx = tid + k * NTHR;
+                const int row = idx / (NT / 4), c4 = idx - row * (NT / 4);
                 const int f0 = l0 + 4 * c4;
                 const bool ok = f0 < L;   // L % 4 == 0: a float4 is inside or outside as a whole
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(cb + (size_t)row * L + min(f0, L - 4));
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4 *>(condT + row * DP_RSC + 4 * c4) = ok ? v : z;
+                *reinterpret_cast<f32x4 *>(condT + row * RS + 4 * c4) = ok ? v : z;
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 32; ++k) {   // 256 rows x 32 frames
-                const int idx = tid + k * 256;
-                const int row = idx >> 5, cc = idx & 31;
+            for (int k = 0; k < 32; ++k) {   // 256 rows x NT frames
+                const int idx = tid + k * NTHR;
+                const int row = idx / NT, cc = idx - row * NT;
                 const int f = l0 + cc;
                 const float v = cb[(size_t)row * L + min(f, L - 1)];
-                condT[row * DP_RSC + cc] = f < L ? v : 0.f;
+                condT[row * RS + cc] = f < L ? v : 0.f;
             }
         }
         const float *xb = a.x_t + (size_t)b * a.M * L;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {   // 96 rows (M = 80 padded) x 32 frames -> hT rows 0..95, col c <-> frame l0+c
-            const int idx = tid + k * 256;
-            const int row = idx >> 5, c = idx & 31;
+        for (int k = 0; k < 12; ++k) {   // 96 rows (M = 80 padded) x NT frames -> hT rows 0..95, col c <-> frame l0+c
+            const int idx = tid + k * NTHR;
+            const int row = idx / NT, c = idx - row * NT;
             const int f = l0 + c;
             const float v = xb[(size_t)min(row, a.M - 1) * L + min(f, L - 1)];
-            hT[row * DP_RSH + c] = (row < a.M && f < L) ? v : 0.f;
+            hT[row * RS + c] = (row < a.M && f < L) ? v : 0.f;
         }
     }
 
-    // residual stream and skip sum of this wave's 64 channels x 32 frames: st[0..1] = x, st[2..3] = skip sum
-    f32x16 st[4];
-    const int rbase = 64 * w;   // first channel of this wave
+    // residual stream and skip sum of this wave's 32*MB channels x NT frames: st[0..MB-1] = x, st[MB..2MB-1] = skip sum
+    f32x16 st[2 * MB][NNB];
+    const int rbase = 32 * MB * w;   // first channel of this wave
     auto row_of = [&](int i, int r) { return rbase + 32 * i + 8 * (r >> 2) + 4 * hh + (r & 3); };
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            st[i][r] = a.in_b[row_of(i, r)];
-            st[2 + i][r] = 0.f;
-        }
+        for (int j = 0; j < NNB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[i][j][r] = a.in_b[row_of(i, r)];
+                st[MB + i][j][r] = 0.f;
+            }
     __syncthreads();
     {   // input projection + ReLU (model/modules.py:430-431)
-        f32x16 acc[2] = {st[0], st[1]};
-        const f32x4 *const ap[2] = {reinterpret_cast<const f32x4 *>(a.in_w) + (size_t)(2 * w) * 12 * 64 + lane,
-                                    reinterpret_cast<const f32x4 *>(a.in_w) + (size_t)(2 * w + 1) * 12 * 64 + lane};
-        dp_mfma_loop<2, DP_RSH, DpIterHead>(acc, ap, hT + hh * DP_RSH + c32);
+        f32x16 acc[MB][NNB];
+        const f32x4 *ap[MB];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MB; ++i) {
+            ap[i] = reinterpret_cast<const f32x4 *>(a.in_w) + (size_t)(MB * w + i) * 12 * 64 + lane;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[i][r] = fmaxf(acc[i][r], 0.f);
+            for (int j = 0; j < NNB; ++j) acc[i][j] = st[i][j];
+        }
+        dp_mfma_loop<MB, NNB, RS, DpIterHead>(acc, ap, hT + hh * RS + c32);
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NNB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[i][j][r] = fmaxf(acc[i][j][r], 0.f);
     }
 
-    const bool fvalid = l0 + c32 < L;   // this lane's frame exists
+    DP_STAMP(1);
+    bool fvalid[NNB];   // this lane's frame of n-block j exists
+#pragma unroll
+    for (int j = 0; j < NNB; ++j) fvalid[j] = l0 + 32 * j + c32 < L;
     dp_gu64 *const gran = (dp_gu64 *)a.gran;
     dp_gu32 *const err = (dp_gu32 *)(a.sync + 1);
 
@@ -252,64 +303,87 @@ __global__ __launch_bounds__(256, 2) void denoiser_persist_kernel(PersistArgs a)
         const float *dv = a.dvec + ((size_t)l * a.B + b) * RB_C;
         const unsigned epoch = a.epoch_base + (unsigned)l + 1u;
         const int par = l & 1;
+        stamp_row = l + 1;
+        DP_STAMP(0);
 
         // ------------------------------------------------------------ GEMM 1: h = Wc cond + bc + x + (Wd s [+ Wp spk])
-        f32x16 acc1[2];
+        f32x16 acc1[MB][NNB];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row_of(i, r);
-                acc1[i][r] = st[i][r] + (lp[a.l_bc + row] + hv[row]);
-            }
+            for (int j = 0; j < NNB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[i][j][r] = st[i][j][r] + (lp[a.l_bc + row_of(i, r)] + hv[row_of(i, r)]);
         {
             const f32x4 *wc = reinterpret_cast<const f32x4 *>(lp + a.l_wc);
-            const f32x4 *const ap[2] = {wc + (size_t)(2 * w) * 32 * 64 + lane, wc + (size_t)(2 * w + 1) * 32 * 64 + lane};
-            dp_mfma_loop<2, DP_RSC, DpIterK1>(acc1, ap, condT + hh * DP_RSC + c32);
+            const f32x4 *ap[MB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) ap[i] = wc + (size_t)(MB * w + i) * 32 * 64 + lane;
+            dp_mfma_loop<MB, NNB, RS, DpIterK1>(acc1, ap, condT + hh * RS + c32);
         }
+        DP_STAMP(1);
+        // GEMM 2's accumulators start at the conv bias: these loads fly during the barrier and the h write-back.
+        // acc2[p][0] = gate rows, acc2[p][1] = filter rows of channels 32*(MB*w + p) .. +31
+        f32x16 acc2[MB][2][NNB];
+#pragma unroll
+        for (int p = 0; p < MB; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = row_of(p, r);
+                const float bg = lp[a.l_b3 + ch], bf = lp[a.l_b3 + RB_C + ch];
+#pragma unroll
+                for (int j = 0; j < NNB; ++j) {
+                    acc2[p][0][j][r] = bg;
+                    acc2[p][1][j][r] = bf;
+                }
+            }
         __syncthreads();   // every wave is past the previous layer's GEMM 3 (or the head GEMM): hT may be rewritten
+        DP_STAMP(2);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                hT[row_of(i, r) * DP_RSH + 1 + c32] = fvalid ? acc1[i][r] : 0.f;   // zero padding of the conv applies to h
+            for (int j = 0; j < NNB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)   // zero padding of the conv applies to h
+                    hT[row_of(i, r) * RS + 1 + 32 * j + c32] = fvalid[j] ? acc1[i][j][r] : 0.f;
         __syncthreads();   // interior columns of hT complete
+        DP_STAMP(3);
 
         // ------------------------------------------------------------ hand the edge columns to the neighbours
-        // wave 0: my frame l0 -> right halo of tile-1;  wave 1: my frame l0+31 -> left halo of tile+1
+        // wave 0: my frame l0 -> right halo of tile-1;  wave 1: my frame l0+NT-1 -> left halo of tile+1
         if (w < 2) {
             const bool go = w == 0 ? has_left : has_right;
             if (go) {
                 const int dst_tile = w == 0 ? tile - 1 : tile + 1;
-                const int col = w == 0 ? 1 : DP_NT;
+                const int col = w == 0 ? 1 : NT;
                 dp_gu64 *g = gran + (((size_t)par * n_tiles + dst_tile) * 2 + (w == 0 ? 1 : 0)) * RB_C;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int row = lane + 64 * k;
-                    const dp_u64 v = ((dp_u64)epoch << 32) | (dp_u64)__float_as_uint(hT[row * DP_RSH + col]);
+                    const dp_u64 v = ((dp_u64)epoch << 32) | (dp_u64)__float_as_uint(hT[row * RS + col]);
                     __hip_atomic_store(g + row, v, DP_RLX_AGENT);   // one aligned 8-byte write-through store per granule
                 }
             }
         }
 
         // ------------------------------------------------------------ GEMM 2, centre tap (needs no halo)
-        // two passes of two 32-row blocks each (gate + filter rows of 32 channels): with all four blocks in one pass the
+        // one pass per 32 channels (two 32-row blocks: gate + filter rows): with all of a wave's blocks in one pass the
         // weight ring alone is 64 VGPRs next to 64 of accumulators and the 64 of x / skip, and the kernel spills
-        f32x16 accA[2], accB[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accA[i][r] = accB[i][r] = 0.f;
         const f32x4 *w3 = reinterpret_cast<const f32x4 *>(lp + a.l_w3);
-        const f32x4 *const apA[2] = {w3 + (size_t)(4 * w) * 96 * 64 + lane, w3 + (size_t)(4 * w + 1) * 96 * 64 + lane};
-        const f32x4 *const apB[2] = {w3 + (size_t)(4 * w + 2) * 96 * 64 + lane, w3 + (size_t)(4 * w + 3) * 96 * 64 + lane};
-        dp_mfma_loop<2, DP_RSH, DpIterCentre>(accA, apA, hT + hh * DP_RSH + c32);
-        dp_mfma_loop<2, DP_RSH, DpIterCentre>(accB, apB, hT + hh * DP_RSH + c32);
+        const f32x4 *ap2[MB][2];
+#pragma unroll
+        for (int p = 0; p < MB; ++p) {
+            ap2[p][0] = w3 + (size_t)(2 * (MB * w + p)) * 96 * 64 + lane;
+            ap2[p][1] = w3 + (size_t)(2 * (MB * w + p) + 1) * 96 * 64 + lane;
+        }
+#pragma unroll
+        for (int p = 0; p < MB; ++p) dp_mfma_loop<2, NNB, RS, DpIterCentre>(acc2[p], ap2[p], hT + hh * RS + c32);
+        DP_STAMP(4);
 
         // ------------------------------------------------------------ receive the halo columns
         if (w < 2) {
             const bool from = w == 0 ? has_left : has_right;
-            const int col = w == 0 ? 0 : DP_NT + 1;
+            const int col = w == 0 ? 0 : NT + 1;
             unsigned v[4] = {0u, 0u, 0u, 0u};
             if (from && s_dead == 0u) {   // after a timeout: keep going (results are garbage), never hang
                 dp_gu64 *g = gran + (((size_t)par * n_tiles + tile) * 2 + w) * RB_C;
@@ -334,86 +408,110 @@ __global__ __launch_bounds__(256, 2) void denoiser_persist_kernel(PersistArgs a)
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) hT[(lane + 64 * k) * DP_RSH + col] = from ? __uint_as_float(v[k]) : 0.f;
+            for (int k = 0; k < 4; ++k) hT[(lane + 64 * k) * RS + col] = from ? __uint_as_float(v[k]) : 0.f;
         }
+        DP_STAMP(5);
         __syncthreads();   // halo columns in place
+        DP_STAMP(6);
 
         // ------------------------------------------------------------ GEMM 2, taps 0 and 2; gate
-        dp_mfma_loop<2, DP_RSH, DpIterOuter>(accA, apA, hT + hh * DP_RSH + c32);
-        dp_mfma_loop<2, DP_RSH, DpIterOuter>(accB, apB, hT + hh * DP_RSH + c32);
-        __syncthreads();   // every wave has read hT for the last time: g may overwrite it
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int chA = row_of(0, r), chB = row_of(1, r);
-            const float sA = mg_sigmoid(accA[0][r] + lp[a.l_b3 + chA]), tA = mg_tanh(accA[1][r] + lp[a.l_b3 + RB_C + chA]);
-            const float sB = mg_sigmoid(accB[0][r] + lp[a.l_b3 + chB]), tB = mg_tanh(accB[1][r] + lp[a.l_b3 + RB_C + chB]);
-            hT[chA * DP_RSH + c32] = sA * tA;
-            hT[chB * DP_RSH + c32] = sB * tB;
-        }
+        for (int p = 0; p < MB; ++p) dp_mfma_loop<2, NNB, RS, DpIterOuter>(acc2[p], ap2[p], hT + hh * RS + c32);
+        DP_STAMP(7);
+        __syncthreads();   // every wave has read hT for the last time: g may overwrite it
+        DP_STAMP(8);
+#pragma unroll
+        for (int p = 0; p < MB; ++p)
+#pragma unroll
+            for (int j = 0; j < NNB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    hT[row_of(p, r) * RS + 32 * j + c32] = mg_sigmoid(acc2[p][0][j][r]) * mg_tanh(acc2[p][1][j][r]);
         // GEMM 3's accumulators start as its addends: x + bo + Wd s and skip + bo (model/blocks.py:1166,1174-1176)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row_of(i, r);
-                st[i][r] += lp[a.l_bo + row] + dv[row];
-                st[2 + i][r] += lp[a.l_bo + RB_C + row];
-            }
+            for (int j = 0; j < NNB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_of(i, r);
+                    st[i][j][r] += lp[a.l_bo + row] + dv[row];
+                    st[MB + i][j][r] += lp[a.l_bo + RB_C + row];
+                }
+        DP_STAMP(9);
         __syncthreads();   // g complete
+        DP_STAMP(10);
 
         // ------------------------------------------------------------ GEMM 3: o = Wo g; x' = (o[:C] + x + Wd s)/sqrt2; skip += o[C:]
         {
             const f32x4 *wo = reinterpret_cast<const f32x4 *>(lp + a.l_wo);
-            const f32x4 *const ap[4] = {wo + (size_t)(2 * w) * 32 * 64 + lane, wo + (size_t)(2 * w + 1) * 32 * 64 + lane,
-                                        wo + (size_t)(8 + 2 * w) * 32 * 64 + lane, wo + (size_t)(9 + 2 * w) * 32 * 64 + lane};
-            dp_mfma_loop<4, DP_RSH, DpIterK1>(st, ap, hT + hh * DP_RSH + c32);
+            const f32x4 *ap[2 * MB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                ap[i] = wo + (size_t)(MB * w + i) * 32 * 64 + lane;            // x rows
+                ap[MB + i] = wo + (size_t)(8 + MB * w + i) * 32 * 64 + lane;   // skip rows
+            }
+            dp_mfma_loop<2 * MB, NNB, RS, DpIterK1>(st, ap, hT + hh * RS + c32);
         }
+        DP_STAMP(11);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[i][r] *= 0.70710678118654752440f;
+            for (int j = 0; j < NNB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[i][j][r] *= 0.70710678118654752440f;
     }
 
     // ---------------------------------------------------------------- tail: sum(skip)/sqrt(NL) -> skip_projection -> ReLU -> output_projection
+    stamp_row = a.NL + 1;
+    DP_STAMP(0);
     __syncthreads();   // last GEMM 3 done reading hT
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hT[row_of(i, r) * DP_RSH + c32] = st[2 + i][r] * a.rsNL;
+        for (int j = 0; j < NNB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hT[row_of(i, r) * RS + 32 * j + c32] = st[MB + i][j][r] * a.rsNL;
     __syncthreads();
     {
-        f32x16 acc[2];
+        f32x16 acc[MB][NNB];
+        const f32x4 *ap[MB];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MB; ++i) {
+            ap[i] = reinterpret_cast<const f32x4 *>(a.skip_w) + (size_t)(MB * w + i) * 32 * 64 + lane;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = a.skip_b[row_of(i, r)];
-        const f32x4 *ws = reinterpret_cast<const f32x4 *>(a.skip_w);
-        const f32x4 *const ap[2] = {ws + (size_t)(2 * w) * 32 * 64 + lane, ws + (size_t)(2 * w + 1) * 32 * 64 + lane};
-        dp_mfma_loop<2, DP_RSH, DpIterK1>(acc, ap, hT + hh * DP_RSH + c32);
+            for (int j = 0; j < NNB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = a.skip_b[row_of(i, r)];
+        }
+        dp_mfma_loop<MB, NNB, RS, DpIterK1>(acc, ap, hT + hh * RS + c32);
         // y -> the cond tile's storage (dead now), col c <-> frame l0+c
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MB; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) condT[row_of(i, r) * DP_RSC + c32] = fmaxf(acc[i][r], 0.f);
+            for (int j = 0; j < NNB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) condT[row_of(i, r) * RS + 32 * j + c32] = fmaxf(acc[i][j][r], 0.f);
     }
     __syncthreads();
     const int mblocks = (a.M + 31) / 32;
-    if (w < mblocks) {   // output projection: M rows in 32-row blocks, one per wave (M <= 128)
-        f32x16 o[1];
+    if (w < mblocks * NNB) {   // output projection: one (32-row block, 32-column block) per wave (M <= 96 or 128)
+        const int mb = w / NNB, nb = w - mb * NNB;
+        f32x16 o[1][1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = 32 * w + 8 * (r >> 2) + 4 * hh + (r & 3);
-            o[0][r] = row < a.M ? a.out_b[row] : 0.f;
+            const int row = 32 * mb + 8 * (r >> 2) + 4 * hh + (r & 3);
+            o[0][0][r] = row < a.M ? a.out_b[row] : 0.f;
         }
-        const f32x4 *const ap[1] = {reinterpret_cast<const f32x4 *>(a.out_w) + (size_t)w * 32 * 64 + lane};
-        dp_mfma_loop<1, DP_RSC, DpIterK1>(o, ap, condT + hh * DP_RSC + c32);
-        const int f = l0 + c32;
+        const f32x4 *const ap[1] = {reinterpret_cast<const f32x4 *>(a.out_w) + (size_t)mb * 32 * 64 + lane};
+        dp_mfma_loop<1, 1, RS, DpIterK1>(o, ap, condT + hh * RS + 32 * nb + c32);
+        const int f = l0 + 32 * nb + c32;
         const size_t bo = (size_t)b * a.M * L;
         if (!a.post) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = 32 * w + 8 * (r >> 2) + 4 * hh + (r & 3);
-                if (row < a.M && f < L) a.out[bo + (size_t)row * L + f] = o[0][r];
+                const int row = 32 * mb + 8 * (r >> 2) + 4 * hh + (r & 3);
+                if (row < a.M && f < L) a.out[bo + (size_t)row * L + f] = o[0][0][r];
             }
         } else {
             // p_sample tail (model/diffusion.py:113-129): clamp, posterior mean, + sigma * noise unless t == 0
@@ -426,17 +524,17 @@ __global__ __launch_bounds__(256, 2) void denoiser_persist_kernel(PersistArgs a)
             float xt[16], nz[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {   // loads first (clamped addresses), math and predicated stores after
-                const int row = min(32 * w + 8 * (r >> 2) + 4 * hh + (r & 3), a.M - 1);
+                const int row = min(32 * mb + 8 * (r >> 2) + 4 * hh + (r & 3), a.M - 1);
                 const size_t e = bo + (size_t)row * L + fc;
                 xt[r] = a.x_t[e];
                 nz[r] = a.noise ? a.noise[e] : dp_normal(seed, off, e);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = 32 * w + 8 * (r >> 2) + 4 * hh + (r & 3);
+                const int row = 32 * mb + 8 * (r >> 2) + 4 * hh + (r & 3);
                 if (row < a.M && f < L) {
                     const size_t e = bo + (size_t)row * L + f;
-                    float x0 = o[0][r];
+                    float x0 = o[0][0][r];
                     if (a.x0_out) a.x0_out[e] = x0;
                     if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
                     a.out[e] = fmaf(sg, nz[r], fmaf(c1, x0, c2 * xt[r]));
@@ -444,12 +542,14 @@ __global__ __launch_bounds__(256, 2) void denoiser_persist_kernel(PersistArgs a)
             }
         }
     }
-    // ---------------------------------------------------------------- last workgroup out re-arms the ticket for the next launch
+    DP_STAMP(1);
+    // ---------------------------------------------------------------- last workgroup out re-arms the tickets for the next launch
     if (tid == 0) {
         const unsigned done = __hip_atomic_fetch_add(a.sync + 3, 1u, DP_RLX_AGENT);
         if (done == (unsigned)n_tiles - 1u) {
             __hip_atomic_store(a.sync + 3, 0u, DP_RLX_AGENT);
             __hip_atomic_store(a.sync, 0u, DP_RLX_AGENT);
+            __hip_atomic_store(a.sync + 16, 0u, DP_RLX_AGENT);
             __hip_atomic_fetch_add(a.sync + 2, 1u, DP_RLX_AGENT);
         }
     }

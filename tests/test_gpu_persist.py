@@ -30,12 +30,14 @@ def _den(mg, manifest, tmp_path, ms=False):
     return den.cuda(), W
 
 
+@pytest.mark.parametrize("nt", [32, 64])
 @pytest.mark.parametrize("ms", [False, True])
-def test_single_launch_forward_vs_oracle_and_per_layer_path(mg, manifest, tmp_path, monkeypatch, ms):
+def test_single_launch_forward_vs_oracle_and_per_layer_path(mg, manifest, tmp_path, monkeypatch, ms, nt):
+    monkeypatch.setenv("MG_PERSIST_NT", str(nt))     # both tile widths, whatever the heuristic would pick
     den, W = _den(mg, manifest, tmp_path, ms)
     gen = torch.Generator().manual_seed(11)
     # one tile, a partial tile, tile boundaries, L % 4 != 0 (scalar staging) and == 0 (float4 staging)
-    for B, L in [(1, 1), (2, 31), (1, 32), (3, 33), (2, 129), (1, 300), (5, 257), (2, 64), (1, 1000)]:
+    for B, L in [(1, 1), (2, 31), (1, 32), (3, 33), (2, 129), (1, 300), (5, 257), (2, 64), (3, 65), (1, 1000)]:
         x = torch.randn(B, 1, 80, L, generator=gen)
         cond = torch.randn(B, 256, L, generator=gen)
         spk = torch.randn(B, 256, generator=gen) if ms else None
@@ -104,10 +106,12 @@ def test_in_kernel_noise_is_standard_normal_and_fresh(mg, manifest, tmp_path):
     assert abs(torch.corrcoef(torch.stack([za.flatten(), zb.flatten()]))[0, 1].item()) < 0.01   # a fresh stream per call
 
 
-def test_full_occupancy_handoffs_are_never_stale(mg, manifest, tmp_path, monkeypatch):
+@pytest.mark.parametrize("nt", [32, 64])
+def test_full_occupancy_handoffs_are_never_stale(mg, manifest, tmp_path, monkeypatch, nt):
     """B=16, L=1000: 512 workgroups, two per CU, every tile waiting on both neighbours in every layer.  The output must be
     bit-identical run after run, with or without a second stream saturating HBM beside it, and identical to what each
     utterance gives alone (other placement, other neighbours in flight); and it must match the per-layer kernels."""
+    monkeypatch.setenv("MG_PERSIST_NT", str(nt))     # 512 workgroups of 32 frames (two per CU) / 256 of 64 frames
     den, W = _den(mg, manifest, tmp_path)
     gen = torch.Generator(device="cuda").manual_seed(16)
     B, L = 16, 1000
@@ -138,9 +142,11 @@ def test_full_occupancy_handoffs_are_never_stale(mg, manifest, tmp_path, monkeyp
     assert_close(first[:1].cpu(), ref, TOL, "vs oracle")
 
 
-def test_more_tiles_than_slots_and_long_utterances(mg, manifest, tmp_path):
-    """B=40, L=1000 = 1280 workgroups on 512 slots (later tiles start as earlier utterances finish), and L=4000 (125-tile
-    chains): finite, deterministic, equal to each sample alone."""
+@pytest.mark.parametrize("nt", [32, 64])
+def test_more_tiles_than_slots_and_long_utterances(mg, manifest, tmp_path, monkeypatch, nt):
+    """B=40, L=1000 = 1280 (640) workgroups on 512 (256) slots (later tiles start as earlier utterances finish), and
+    L=4000 (125- / 63-tile chains): finite, deterministic, equal to each sample alone."""
+    monkeypatch.setenv("MG_PERSIST_NT", str(nt))
     den, _ = _den(mg, manifest, tmp_path)
     gen = torch.Generator(device="cuda").manual_seed(40)
     for B, L in [(40, 1000), (6, 4000)]:
