@@ -36,10 +36,18 @@ K3_FLOP_PER_FRAME = 2 * 512 * 768      # generic path's dominant kernel: Conv1d(
 # k=3 conv 256->512 + conditioner 1x1 256->256 + output 1x1 256->512 (algorithmic; halo MFMAs not counted)
 LAYER_FLOP_PER_FRAME = 2 * 512 * 768 + 2 * 256 * 256 + 2 * 512 * 256
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-# HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (profiles/r01_d_pmc_*.json):
-# (2 x FETCH_SIZE + WRITE_SIZE) x 1024 with the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md section HBM
-# (an upper bound here: only the 16-B/lane loads are under-counted); B=16, L=1000 only.
-TRAFFIC_BYTES = {"fp32": int((2 * 57156.66 + 32000.04) * 1024), "bf16x3": None}
+# roofline.traffic is NOT measured in this run (PMC counters need their own rocprofv3 passes): it is read from the
+# tracked profile summary profiles/bench_traffic.json (written from tools/profile_bench.sh's passes over this same
+# command), and the line says so in roofline.traffic_source.  Default shape, fp32, single-launch kernel only.
+
+
+def tracked_traffic():
+    try:
+        with open(os.path.join(ROOT, "profiles", "bench_traffic.json")) as f:
+            t = json.load(f)
+        return int(t["traffic_bytes_per_launch"]), t["source"]
+    except Exception:
+        return None, None
 
 
 def main():
@@ -139,10 +147,10 @@ def main():
             # (mg_denoiser_psample; a single kernel launch on the fp32 path)
             gd._p_sample_bml(xin, ts[(T - 1 - i) % T], cond, None, None, True, out=xout, packed=pk)
 
-        cur = x
+        cur, nxt = x, 0           # x_{t-1} never aliases x_t: ping-pong between the two buffers
         for i in range(args.warmup):
-            step_(i, cur, bufs[i & 1])
-            cur = bufs[i & 1]
+            step_(i, cur, bufs[nxt])
+            cur, nxt = bufs[nxt], nxt ^ 1
         single = single_launch(precision)
         n_layers = 1 if single else len(den.residual_layers)
         Lh = _lib.lib()
@@ -154,8 +162,8 @@ def main():
         sync()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            step_(i, cur, bufs[i & 1])
-            cur = bufs[i & 1]
+            step_(i, cur, bufs[nxt])
+            cur, nxt = bufs[nxt], nxt ^ 1
         sync()
         dt = time.perf_counter() - t0
         ms = (ctypes.c_float * (args.steps * n_layers))()
@@ -199,10 +207,11 @@ def main():
                          "vs_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 3)}
             r = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                  "frac": round(achieved / peak, 4),
-                 "traffic": TRAFFIC_BYTES.get(precision) if (B, L) == (B_PER_GPU, L_FRAMES) and not single else None,
-                 "kernel_ms": round(k_ms, 4),
+                 "traffic": None, "kernel_ms": round(k_ms, 4),
                  "launches_timed": n_ev, "whole_step_tflops": round(whole, 2),
                  "whole_step_frac": round(whole / peak, 4)}
+            if single and precision == "fp32" and (B, L) == (B_PER_GPU, L_FRAMES):
+                r["traffic"], r["traffic_source"] = tracked_traffic()
             r.update(extra)
             return r
 

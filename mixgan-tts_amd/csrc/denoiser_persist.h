@@ -17,9 +17,10 @@
 //            stream is read once per 64 frames.  Used when it fills the chip (B x ceil(L/64) > 128 workgroups).
 //   NT = 32: 4 waves, wave w owns channels 64w..64w+63 x 32 frames; two workgroups per CU (2 x 74 KB); twice the
 //            workgroups for small batches / single utterances, at twice the weight stream per frame.
-// LDS: condT [256][NT+4]  col j <-> frame l0+j     (16-byte aligned rows for float4 staging); lives all layers
-//      hT    [256][NT+4]  col j <-> frame l0-1+j   h of the current layer incl. the two halo columns; overwritten in
-//                         place by g = sigmoid * tanh (col j <-> frame l0+j) once GEMM 2 has read it
+// LDS: condT 256 channels x NT columns    col j <-> frame l0+j     lives all layers
+//      hT    256 channels x NT+2 columns  col j <-> frame l0-1+j   h of the current layer incl. the two halo columns;
+//                         overwritten in place by g = sigmoid * tanh (col j <-> frame l0+j) once GEMM 2 has read it
+//      both k-interleaved (dp_at): a lane's B fragments of a k-group are one ds_read_b128
 // Forward progress: tiles are handed out by atomic tickets in START order, so a workgroup only ever waits for workgroups
 // that have started or will start as soon as a slot frees; an utterance's tiles are consecutive tickets, and the launcher
 // uses this kernel only when an utterance's chain fits in a quarter of the chip's slots.  Every spin is bounded (a
@@ -82,21 +83,30 @@ struct DpIterOuter {   // k=3 conv, taps 0 and 2
     static __device__ __forceinline__ int tap(int it) { return (it & 1) * 2; }
 };
 
+// LDS tile layout ("k-interleaved"): T[g][col][8] floats, g = channel / 8, and inside the 8: channel k = 2e + hh sits at
+// position hh * 4 + e.  The B fragments of one k-group (the four 32x32x2 MFMAs' k = 2e + hh, e = 0..3) of a lane are
+// then 16 contiguous bytes: ONE ds_read_b128 per k-group and 32-column block (4 LDS cycles) where the row-major tile
+// took two ds_read2_b32 (16 LDS cycles).  Measured (tools/ubench/mfma_f32_loop.hip): LDS read instructions, not the
+// weight loads, are what pushes the f32 MFMA off its 64-cycle cadence.
+__device__ __forceinline__ int dp_pos(int ch) { return ((ch & 1) << 2) | ((ch >> 1) & 3); }
+template <int NTC>
+__device__ __forceinline__ int dp_at(int ch, int col) { return (((ch >> 3) * NTC + col) << 3) + dp_pos(ch); }
+
 // k loop of one GEMM phase for NMB 32-row blocks x NNB 32-column blocks.  Register pipeline as in rb_mfma_loop
 // (resblock_fused.h): weight float4s DIST k-groups ahead in a ring of 4, LDS B fragments one k-group ahead; the
 // prefetches are pinned at the TOP of each k-group with sched_barrier (left alone, hipcc sinks them to the end of the
 // group: one k-group of latency cover instead of DIST) and the MFMAs keep the written order, which never puts two MFMAs
 // on one accumulator back to back.  The iteration order over (chunk, tap) comes from IT.
 //   ap[i]: packed weights of block i (+ lane); k-group q of (chunk, tap) = (chunk * KW + tap) * 4 + g sits at ap[i][q * 64]
-//   tile:  LDS tile + hh * RS + (this lane's column of n-block 0 for tap 0)
-template <int NMB, int NNB, int RS, class IT, int DIST = (NMB * NNB >= 4 ? 2 : 3)>
+//   tile:  k-interleaved LDS tile + (this lane's column of n-block 0 for tap 0) * 8 + hh * 4;  NTC: its columns
+template <int NMB, int NNB, int NTC, class IT, int DIST = (NMB * NNB >= 4 ? 2 : 3)>
 __device__ __forceinline__ void dp_mfma_loop(f32x16 (&acc)[NMB][NNB], const f32x4 *const (&ap)[NMB], const float *__restrict__ tile)
 {
     static_assert(DIST >= 1 && DIST <= 3, "ring of 4 slots");
     f32x4 ring[4][NMB];
-    float bb[2][4][NNB];
+    f32x4 bb[2][NNB];
     auto qbase = [](int it) { return (IT::chunk(it) * IT::KW + IT::tap(it)) * 4; };
-    auto boff = [](int it) { return IT::chunk(it) * (32 * RS) + IT::tap(it); };
+    auto boff = [](int it) { return IT::chunk(it) * (4 * NTC * 8) + IT::tap(it) * 8; };
     {
         const int q0 = qbase(0);
 #pragma unroll
@@ -105,9 +115,7 @@ __device__ __forceinline__ void dp_mfma_loop(f32x16 (&acc)[NMB][NNB], const f32x
             for (int i = 0; i < NMB; ++i) ring[s][i] = ap[i][(size_t)(q0 + s) * 64];
         const float *T0 = tile + boff(0);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int j = 0; j < NNB; ++j) bb[0][e][j] = T0[(2 * e) * RS + 32 * j];
+        for (int j = 0; j < NNB; ++j) bb[0][j] = *reinterpret_cast<const f32x4 *>(T0 + 32 * 8 * j);
     }
 #pragma unroll 1   // keep the layer's code inside the instruction cache
     for (int it = 0; it < IT::N; ++it) {
@@ -120,11 +128,9 @@ __device__ __forceinline__ void dp_mfma_loop(f32x16 (&acc)[NMB][NNB], const f32x
 #pragma unroll
             for (int i = 0; i < NMB; ++i) ring[(u + DIST) & 3][i] = ap[i][(size_t)qa * 64];
             {
-                const float *Tx = u < 3 ? Tc + ((u + 1) * 8) * RS : Tn;
+                const float *Tx = u < 3 ? Tc + (u + 1) * (NTC * 8) : Tn;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int j = 0; j < NNB; ++j) bb[(u + 1) & 1][e][j] = Tx[(2 * e) * RS + 32 * j];
+                for (int j = 0; j < NNB; ++j) bb[(u + 1) & 1][j] = *reinterpret_cast<const f32x4 *>(Tx + 32 * 8 * j);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -133,11 +139,25 @@ __device__ __forceinline__ void dp_mfma_loop(f32x16 (&acc)[NMB][NNB], const f32x
                 for (int i = 0; i < NMB; ++i)
 #pragma unroll
                     for (int j = 0; j < NNB; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[u][i][e], bb[u & 1][e][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[u][i][e], bb[u & 1][j][e], acc[i][j], 0, 0, 0);
                 if (NMB * NNB < 4) __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+}
+
+// write the 16 accumulator registers of one 32x32 block (rows ch0 + 8 (r >> 2) + 4 hh + (r & 3), this lane's column)
+// into a k-interleaved tile: registers (0, 2) and (1, 3) of every quad are adjacent there -> 8 ds_write_b64
+template <int NTC, class F>
+__device__ __forceinline__ void dp_store_block(float *T, int ch0, int col, int hh, F val)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float *base = T + ((((ch0 >> 3) + q) * NTC + col) << 3);
+        const f32x2 lo = {val(4 * q + 0), val(4 * q + 2)}, hi = {val(4 * q + 1), val(4 * q + 3)};
+        *reinterpret_cast<f32x2 *>(base + 2 * hh) = lo;       // channels 4hh, 4hh+2  -> positions 2hh, 2hh+1
+        *reinterpret_cast<f32x2 *>(base + 4 + 2 * hh) = hi;   // channels 4hh+1, 4hh+3 -> positions 4+2hh, 5+2hh
     }
 }
 
@@ -179,11 +199,11 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
     constexpr int NTHR = NT * 8, NW = NTHR / 64;    // threads, waves
     constexpr int MB = 8 / NW;                      // 32-row blocks of the 256 channels per wave: 2 (NT = 32) or 1
     constexpr int NNB = NT / 32;                    // 32-column blocks per tile
-    constexpr int RS = NT + 4;                      // LDS row stride of both tiles
-    __shared__ __attribute__((aligned(16))) float lds[2 * RB_C * RS];
+    constexpr int NC = NT, NH = NT + 2;             // columns of the cond tile and of the h tile (k-interleaved: dp_at)
+    __shared__ __attribute__((aligned(16))) float lds[RB_C * (NC + NH)];
     __shared__ unsigned s_tile, s_dead, s_launch;
-    float *condT = lds;
-    float *hT = lds + RB_C * RS;
+    float *condT = lds;                             // col j <-> frame l0+j
+    float *hT = lds + RB_C * NC;                    // col j <-> frame l0-1+j (h), or frame l0+j (x_t, g, skip sum)
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int hh = lane >> 5, c32 = lane & 31;
@@ -234,8 +254,8 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
                 const int f0 = l0 + 4 * c4;
                 const bool ok = f0 < L;   // L % 4 == 0: a float4 is inside or outside as a whole
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(cb + (size_t)row * L + min(f0, L - 4));
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4 *>(condT + row * RS + 4 * c4) = ok ? v : z;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) condT[dp_at<NC>(row, 4 * c4 + e)] = ok ? v[e] : 0.f;
             }
         } else {
 #pragma unroll
@@ -244,17 +264,17 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
                 const int row = idx / NT, cc = idx - row * NT;
                 const int f = l0 + cc;
                 const float v = cb[(size_t)row * L + min(f, L - 1)];
-                condT[row * RS + cc] = f < L ? v : 0.f;
+                condT[dp_at<NC>(row, cc)] = f < L ? v : 0.f;
             }
         }
         const float *xb = a.x_t + (size_t)b * a.M * L;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {   // 96 rows (M = 80 padded) x NT frames -> hT rows 0..95, col c <-> frame l0+c
+        for (int k = 0; k < 12; ++k) {   // 96 rows (M = 80 padded) x NT frames -> hT channels 0..95, col c <-> frame l0+c
             const int idx = tid + k * NTHR;
             const int row = idx / NT, c = idx - row * NT;
             const int f = l0 + c;
             const float v = xb[(size_t)min(row, a.M - 1) * L + min(f, L - 1)];
-            hT[row * RS + c] = (row < a.M && f < L) ? v : 0.f;
+            hT[dp_at<NH>(row, c)] = (row < a.M && f < L) ? v : 0.f;
         }
     }
 
@@ -281,7 +301,7 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
 #pragma unroll
             for (int j = 0; j < NNB; ++j) acc[i][j] = st[i][j];
         }
-        dp_mfma_loop<MB, NNB, RS, DpIterHead>(acc, ap, hT + hh * RS + c32);
+        dp_mfma_loop<MB, NNB, NH, DpIterHead>(acc, ap, hT + c32 * 8 + hh * 4);
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -319,7 +339,7 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
             const f32x4 *ap[MB];
 #pragma unroll
             for (int i = 0; i < MB; ++i) ap[i] = wc + (size_t)(MB * w + i) * 32 * 64 + lane;
-            dp_mfma_loop<MB, NNB, RS, DpIterK1>(acc1, ap, condT + hh * RS + c32);
+            dp_mfma_loop<MB, NNB, NC, DpIterK1>(acc1, ap, condT + c32 * 8 + hh * 4);
         }
         DP_STAMP(1);
         // GEMM 2's accumulators start at the conv bias: these loads fly during the barrier and the h write-back.
@@ -343,9 +363,8 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
         for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int j = 0; j < NNB; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)   // zero padding of the conv applies to h
-                    hT[row_of(i, r) * RS + 1 + 32 * j + c32] = fvalid[j] ? acc1[i][j][r] : 0.f;
+            dp_store_block<NH>(hT, rbase + 32 * i, 1 + 32 * j + c32, hh,   // zero padding of the conv applies to h
+                               [&](int r) { return fvalid[j] ? acc1[i][j][r] : 0.f; });
         __syncthreads();   // interior columns of hT complete
         DP_STAMP(3);
 
@@ -360,7 +379,7 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int row = lane + 64 * k;
-                    const dp_u64 v = ((dp_u64)epoch << 32) | (dp_u64)__float_as_uint(hT[row * RS + col]);
+                    const dp_u64 v = ((dp_u64)epoch << 32) | (dp_u64)__float_as_uint(hT[dp_at<NH>(row, col)]);
                     __hip_atomic_store(g + row, v, DP_RLX_AGENT);   // one aligned 8-byte write-through store per granule
                 }
             }
@@ -377,7 +396,7 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
             ap2[p][1] = w3 + (size_t)(2 * (MB * w + p) + 1) * 96 * 64 + lane;
         }
 #pragma unroll
-        for (int p = 0; p < MB; ++p) dp_mfma_loop<2, NNB, RS, DpIterCentre>(acc2[p], ap2[p], hT + hh * RS + c32);
+        for (int p = 0; p < MB; ++p) dp_mfma_loop<2, NNB, NH, DpIterCentre>(acc2[p], ap2[p], hT + c32 * 8 + hh * 4);
         DP_STAMP(4);
 
         // ------------------------------------------------------------ receive the halo columns
@@ -408,7 +427,7 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) hT[(lane + 64 * k) * RS + col] = from ? __uint_as_float(v[k]) : 0.f;
+            for (int k = 0; k < 4; ++k) hT[dp_at<NH>(lane + 64 * k, col)] = from ? __uint_as_float(v[k]) : 0.f;
         }
         DP_STAMP(5);
         __syncthreads();   // halo columns in place
@@ -416,7 +435,7 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
 
         // ------------------------------------------------------------ GEMM 2, taps 0 and 2; gate
 #pragma unroll
-        for (int p = 0; p < MB; ++p) dp_mfma_loop<2, NNB, RS, DpIterOuter>(acc2[p], ap2[p], hT + hh * RS + c32);
+        for (int p = 0; p < MB; ++p) dp_mfma_loop<2, NNB, NH, DpIterOuter>(acc2[p], ap2[p], hT + c32 * 8 + hh * 4);
         DP_STAMP(7);
         __syncthreads();   // every wave has read hT for the last time: g may overwrite it
         DP_STAMP(8);
@@ -424,9 +443,8 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
         for (int p = 0; p < MB; ++p)
 #pragma unroll
             for (int j = 0; j < NNB; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    hT[row_of(p, r) * RS + 32 * j + c32] = mg_sigmoid(acc2[p][0][j][r]) * mg_tanh(acc2[p][1][j][r]);
+            dp_store_block<NH>(hT, rbase + 32 * p, 32 * j + c32, hh,
+                               [&](int r) { return mg_sigmoid(acc2[p][0][j][r]) * mg_tanh(acc2[p][1][j][r]); });
         // GEMM 3's accumulators start as its addends: x + bo + Wd s and skip + bo (model/blocks.py:1166,1174-1176)
 #pragma unroll
         for (int i = 0; i < MB; ++i)
@@ -451,7 +469,7 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
                 ap[i] = wo + (size_t)(MB * w + i) * 32 * 64 + lane;            // x rows
                 ap[MB + i] = wo + (size_t)(8 + MB * w + i) * 32 * 64 + lane;   // skip rows
             }
-            dp_mfma_loop<2 * MB, NNB, RS, DpIterK1>(st, ap, hT + hh * RS + c32);
+            dp_mfma_loop<2 * MB, NNB, NH, DpIterK1>(st, ap, hT + c32 * 8 + hh * 4);
         }
         DP_STAMP(11);
 #pragma unroll
@@ -470,8 +488,7 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
     for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int j = 0; j < NNB; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hT[row_of(i, r) * RS + 32 * j + c32] = st[MB + i][j][r] * a.rsNL;
+            dp_store_block<NH>(hT, rbase + 32 * i, 32 * j + c32, hh, [&](int r) { return st[MB + i][j][r] * a.rsNL; });
     __syncthreads();
     {
         f32x16 acc[MB][NNB];
@@ -484,14 +501,13 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = a.skip_b[row_of(i, r)];
         }
-        dp_mfma_loop<MB, NNB, RS, DpIterK1>(acc, ap, hT + hh * RS + c32);
+        dp_mfma_loop<MB, NNB, NH, DpIterK1>(acc, ap, hT + c32 * 8 + hh * 4);
         // y -> the cond tile's storage (dead now), col c <-> frame l0+c
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int j = 0; j < NNB; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) condT[row_of(i, r) * RS + 32 * j + c32] = fmaxf(acc[i][j][r], 0.f);
+                dp_store_block<NC>(condT, rbase + 32 * i, 32 * j + c32, hh, [&](int r) { return fmaxf(acc[i][j][r], 0.f); });
     }
     __syncthreads();
     const int mblocks = (a.M + 31) / 32;
@@ -504,7 +520,7 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
             o[0][0][r] = row < a.M ? a.out_b[row] : 0.f;
         }
         const f32x4 *const ap[1] = {reinterpret_cast<const f32x4 *>(a.out_w) + (size_t)mb * 32 * 64 + lane};
-        dp_mfma_loop<1, 1, RS, DpIterK1>(o, ap, condT + hh * RS + 32 * nb + c32);
+        dp_mfma_loop<1, 1, NC, DpIterK1>(o, ap, condT + (32 * nb + c32) * 8 + hh * 4);
         const int f = l0 + 32 * nb + c32;
         const size_t bo = (size_t)b * a.M * L;
         if (!a.post) {

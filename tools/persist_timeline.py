@@ -28,7 +28,8 @@ den = gd.denoise_fn
 x = torch.randn(B, 80, L, device="cuda")
 cond = torch.randn(B, 256, L, device="cuda")
 t = torch.full((B,), 3, device="cuda", dtype=torch.long)
-tiles = B * ((L + 31) // 32)
+NT = int(os.environ.get('MG_PERSIST_NT', 64 if B * ((L + 63) // 64) > 128 else 32))
+tiles = B * ((L + NT - 1) // NT)
 for _ in range(3):
     den.run(x, t, cond, None)
 stamps = torch.zeros(tiles * (NL + 2) * 12, dtype=torch.int64, device="cuda")
@@ -41,7 +42,8 @@ lib.mg_debug_persist_stamps(ctypes.c_void_p(0))
 s = stamps.cpu().numpy().reshape(tiles, NL + 2, 12).astype(np.float64)
 t0 = s[:, 0, 0].min()
 lay = s[:, 1:NL + 1, :]                       # [tiles, NL, 12]
-names = ["GEMM1 (init + k loop)", "barrier (prev GEMM3 done)", "h write + barrier", "publish + GEMM2 centre",
+names = [  # NT-independent
+         "GEMM1 (init + k loop)", "barrier (prev GEMM3 done)", "h write + barrier", "publish + GEMM2 centre",
          "halo sweep (wave 0)", "barrier (halo in place)", "GEMM2 outer", "barrier (hT read done)", "gate + addends",
          "barrier (g complete)", "GEMM3"]
 d = np.diff(lay, axis=2)                      # [tiles, NL, 11]

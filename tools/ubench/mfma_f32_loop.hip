@@ -7,10 +7,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k(const f32x4 *__restrict__ w, float *out, long long *cyc, int iters)
+__global__ __launch_bounds__(512) void k(const f32x4 *__restrict__ w, float *out, long long *cyc, int iters)
 {
     __shared__ float lds[256 * 36];
-    for (int i = threadIdx.x; i < 256 * 36; i += 256) lds[i] = i * 1e-4f;
+    for (int i = threadIdx.x; i < 256 * 36; i += blockDim.x) lds[i] = i * 1e-4f;
     __syncthreads();
     const int lane = threadIdx.x & 63, hh = lane >> 5, c32 = lane & 31;
     f32x16 acc[2];
@@ -66,24 +66,26 @@ __global__ __launch_bounds__(256) void k(const f32x4 *__restrict__ w, float *out
     for (int i = 0; i < 2; ++i)
         for (int r = 0; r < 16; ++r) s += acc[i][r];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-    if (lane == 0) cyc[blockIdx.x * 4 + threadIdx.x / 64] = t1 - t0;
+    if (lane == 0) cyc[blockIdx.x * 8 + threadIdx.x / 64] = t1 - t0;
 }
 
 template <class K>
-static void run(const char *name, K kern, const f32x4 *w)
+static void run(const char *name, K kern, const f32x4 *w, int threads)
 {
-    const int blocks = 256, iters = 1000;
+    const int blocks = 256, iters = 1000, nw = threads / 64;
     float *out;
-    long long *cyc, h[1024];
-    hipMalloc(&out, blocks * 256 * 4);
-    hipMalloc(&cyc, blocks * 4 * 8);
-    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, w, out, cyc, iters);
+    long long *cyc, h[2048];
+    hipMalloc(&out, blocks * 512 * 4);
+    hipMalloc(&cyc, blocks * 8 * 8);
+    hipMemset(cyc, 0, blocks * 8 * 8);
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, w, out, cyc, iters);
     hipDeviceSynchronize();
-    hipMemcpy(h, cyc, blocks * 4 * 8, hipMemcpyDeviceToHost);
+    hipMemcpy(h, cyc, blocks * 8 * 8, hipMemcpyDeviceToHost);
     double mean = 0;
-    for (int i = 0; i < blocks * 4; ++i) mean += (double)h[i];
-    mean /= blocks * 4;
-    printf("%-60s %.1f cycles per MFMA\n", name, mean / (iters * 32.0));
+    for (int b = 0; b < blocks; ++b)
+        for (int i = 0; i < nw; ++i) mean += (double)h[b * 8 + i];
+    mean /= blocks * nw;
+    printf("%d waves/SIMD  %-58s %.1f cycles per MFMA per SIMD\n", nw / 4, name, mean / (iters * 32.0) / (nw / 4));
     hipFree(out);
     hipFree(cyc);
 }
@@ -93,11 +95,13 @@ int main()
     f32x4 *w;
     hipMalloc(&w, 4 << 20);
     hipMemset(w, 0, 4 << 20);
-    run("(a) fixed operands", k<0>, w);
-    run("(b) a fresh A / B register per MFMA", k<1>, w);
-    run("(c) b + 2 ds_read2_b32 per 8 MFMAs", k<2>, w);
-    run("(d) b + 2 global_load_dwordx4 per 8 MFMAs", k<3>, w);
-    run("(e) b + both", k<4>, w);
-    run("(f) e, one memory instruction behind each of 4 MFMAs", k<5>, w);
+    for (int th : {256, 512}) {
+        run("(a) fixed operands", k<0>, w, th);
+        run("(b) a fresh A / B register per MFMA", k<1>, w, th);
+        run("(c) b + 2 ds_read2_b32 per 8 MFMAs", k<2>, w, th);
+        run("(d) b + 2 global_load_dwordx4 per 8 MFMAs", k<3>, w, th);
+        run("(e) b + both", k<4>, w, th);
+        run("(f) e, one memory instruction behind each of 4 MFMAs", k<5>, w, th);
+    }
     return 0;
 }
