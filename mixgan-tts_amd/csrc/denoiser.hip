@@ -580,7 +580,7 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
     }
     const int tiles_per_b = mg_cdiv(L, nt);
     const int chain_cap = nt == 64 ? 64 : 128;   // a quarter of the 256 / 512 slots
-    if (fused && !no_persist && !save && !split && M <= 96 && NL >= 3 && tiles_per_b <= chain_cap) {
+    if (fused && !no_persist && !split && M <= 96 && NL >= 3 && tiles_per_b <= chain_cap) {
         PersistArgs a;
         a.x_t = x_t;
         a.cond = cond;
@@ -621,6 +621,14 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
         a.n_steps = post ? post->n_steps : 1;
         a.rsNL = 1.0f / sqrtf((float)NL);
         a.dbg = g_persist_dbg;
+        a.x0_save = save ? ws + w.x0 : nullptr;
+        a.y_save = save ? ws + w.y : nullptr;
+        a.skip_save = save ? ws + w.skip : nullptr;
+        a.h_save = save ? ws + w.h : nullptr;
+        a.g_save = save ? ws + w.g : nullptr;
+        a.sig_save = save ? ws + w.sig : nullptr;
+        a.tnh_save = save ? ws + w.tnh : nullptr;
+        a.act_stride = w.act_stride;
         {
             const char *fe = std::getenv("MG_PERSIST_FLAGS");
             a.flags = fe ? std::atoi(fe) : DP_F_ROLES;
@@ -628,15 +636,21 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
         const bool vec4 = (L % 4 == 0) && (((uintptr_t)cond & 15) == 0);
         dim3 grid((unsigned)(tiles_per_b * B));
         prof_mark(st, 0);
-#define MG_DP_LAUNCH(NT, V, T) hipLaunchKernelGGL((denoiser_persist_kernel<NT, V, T>), grid, dim3(NT * 8), 0, st, a)
+#define MG_DP_LAUNCH(NT, V, T, S) hipLaunchKernelGGL((denoiser_persist_kernel<NT, V, T, S>), grid, dim3(NT * 8), 0, st, a)
         if (nt == 64) {
-            if (g_persist_dbg && vec4) MG_DP_LAUNCH(64, true, true);
-            else if (vec4) MG_DP_LAUNCH(64, true, false);
-            else MG_DP_LAUNCH(64, false, false);
+            if (save) {
+                if (vec4) MG_DP_LAUNCH(64, true, false, true);
+                else MG_DP_LAUNCH(64, false, false, true);
+            } else if (g_persist_dbg && vec4) MG_DP_LAUNCH(64, true, true, false);
+            else if (vec4) MG_DP_LAUNCH(64, true, false, false);
+            else MG_DP_LAUNCH(64, false, false, false);
         } else {
-            if (g_persist_dbg && vec4) MG_DP_LAUNCH(32, true, true);
-            else if (vec4) MG_DP_LAUNCH(32, true, false);
-            else MG_DP_LAUNCH(32, false, false);
+            if (save) {
+                if (vec4) MG_DP_LAUNCH(32, true, false, true);
+                else MG_DP_LAUNCH(32, false, false, true);
+            } else if (g_persist_dbg && vec4) MG_DP_LAUNCH(32, true, true, false);
+            else if (vec4) MG_DP_LAUNCH(32, true, false, false);
+            else MG_DP_LAUNCH(32, false, false, false);
         }
 #undef MG_DP_LAUNCH
         prof_mark(st, 1);

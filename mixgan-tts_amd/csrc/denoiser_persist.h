@@ -55,6 +55,10 @@ struct PersistArgs {
     unsigned *sync;                       // [0] / [16] tickets, [1] error (sticky), [2] launches completed, [3] workgroups done;
                                           // zero once at allocation: the last workgroup out re-arms [0], [16] and [3]
     unsigned epoch_base;
+    // SAVE instantiation (training forward): what mg_denoiser_bwd consumes, all [B, 256, L]
+    float *x0_save, *y_save, *skip_save;  // ReLU outputs of the input / skip projections, raw skip sum
+    float *h_save, *g_save, *sig_save, *tnh_save;   // per layer (stride act_stride floats): h, gate product, sigmoid, tanh
+    size_t act_stride;
     unsigned long long *dbg;              // TIMING instantiation only: [tiles][NL + 2][12] cycle stamps of lane 0
     int B, L, M, NL, tiles_per_b, post, clip, n_steps;
     int flags;                            // DP_F_*
@@ -192,7 +196,7 @@ __device__ __forceinline__ float dp_normal(unsigned long long seed, unsigned lon
 #define DP_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 #define DP_STAMP(k) do { if (TIMING && tid == 0) a.dbg[((size_t)tile * (a.NL + 2) + stamp_row) * 12 + (k)] = clock64(); } while (0)
 
-template <int NT, bool VEC4, bool TIMING = false>
+template <int NT, bool VEC4, bool TIMING = false, bool SAVE = false>
 __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs a)
 {
     static_assert(NT == 32 || NT == 64, "tile widths: 32 (4 waves, two workgroups per CU) or 64 (8 waves, one)");
@@ -309,11 +313,26 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
 #pragma unroll
                 for (int r = 0; r < 16; ++r) st[i][j][r] = fmaxf(acc[i][j][r], 0.f);
     }
-
+    (void)0;
     DP_STAMP(1);
     bool fvalid[NNB];   // this lane's frame of n-block j exists
+    const size_t bbase = (size_t)b * RB_C * L;
+    // SAVE: one 32x32 block (channels ch0.., this lane's frame of n-block j) to a [B, 256, L] tensor
+    auto save_block = [&](float *dst, int ch0, int j, auto val) {
+        const int f = l0 + 32 * j + c32;
+        if (f < L) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[bbase + (size_t)(ch0 + 8 * (r >> 2) + 4 * hh + (r & 3)) * L + f] = val(r);
+        }
+    };
 #pragma unroll
     for (int j = 0; j < NNB; ++j) fvalid[j] = l0 + 32 * j + c32 < L;
+    if (SAVE) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NNB; ++j) save_block(a.x0_save, rbase + 32 * i, j, [&](int r) { return st[i][j][r]; });
+    }
     dp_gu64 *const gran = (dp_gu64 *)a.gran;
     dp_gu32 *const err = (dp_gu32 *)(a.sync + 1);
 
@@ -363,8 +382,11 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
         for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int j = 0; j < NNB; ++j)
-            dp_store_block<NH>(hT, rbase + 32 * i, 1 + 32 * j + c32, hh,   // zero padding of the conv applies to h
-                               [&](int r) { return fvalid[j] ? acc1[i][j][r] : 0.f; });
+            {
+                dp_store_block<NH>(hT, rbase + 32 * i, 1 + 32 * j + c32, hh,   // zero padding of the conv applies to h
+                                   [&](int r) { return fvalid[j] ? acc1[i][j][r] : 0.f; });
+                if (SAVE) save_block(a.h_save + (size_t)l * a.act_stride, rbase + 32 * i, j, [&](int r) { return acc1[i][j][r]; });
+            }
         __syncthreads();   // interior columns of hT complete
         DP_STAMP(3);
 
@@ -443,8 +465,23 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
         for (int p = 0; p < MB; ++p)
 #pragma unroll
             for (int j = 0; j < NNB; ++j)
-            dp_store_block<NH>(hT, rbase + 32 * p, 32 * j + c32, hh,
-                               [&](int r) { return mg_sigmoid(acc2[p][0][j][r]) * mg_tanh(acc2[p][1][j][r]); });
+            {
+                if (SAVE) {   // the backward's gate derivative needs sigmoid and tanh themselves
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        acc2[p][0][j][r] = mg_sigmoid(acc2[p][0][j][r]);
+                        acc2[p][1][j][r] = mg_tanh(acc2[p][1][j][r]);
+                    }
+                    const size_t lo = (size_t)l * a.act_stride;
+                    save_block(a.sig_save + lo, rbase + 32 * p, j, [&](int r) { return acc2[p][0][j][r]; });
+                    save_block(a.tnh_save + lo, rbase + 32 * p, j, [&](int r) { return acc2[p][1][j][r]; });
+                    save_block(a.g_save + lo, rbase + 32 * p, j, [&](int r) { return acc2[p][0][j][r] * acc2[p][1][j][r]; });
+                    dp_store_block<NH>(hT, rbase + 32 * p, 32 * j + c32, hh, [&](int r) { return acc2[p][0][j][r] * acc2[p][1][j][r]; });
+                } else {
+                    dp_store_block<NH>(hT, rbase + 32 * p, 32 * j + c32, hh,
+                                       [&](int r) { return mg_sigmoid(acc2[p][0][j][r]) * mg_tanh(acc2[p][1][j][r]); });
+                }
+            }
         // GEMM 3's accumulators start as its addends: x + bo + Wd s and skip + bo (model/blocks.py:1166,1174-1176)
 #pragma unroll
         for (int i = 0; i < MB; ++i)
@@ -488,7 +525,10 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
     for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int j = 0; j < NNB; ++j)
-            dp_store_block<NH>(hT, rbase + 32 * i, 32 * j + c32, hh, [&](int r) { return st[MB + i][j][r] * a.rsNL; });
+            {
+                dp_store_block<NH>(hT, rbase + 32 * i, 32 * j + c32, hh, [&](int r) { return st[MB + i][j][r] * a.rsNL; });
+                if (SAVE) save_block(a.skip_save, rbase + 32 * i, j, [&](int r) { return st[MB + i][j][r]; });
+            }
     __syncthreads();
     {
         f32x16 acc[MB][NNB];
@@ -507,7 +547,10 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
         for (int i = 0; i < MB; ++i)
 #pragma unroll
             for (int j = 0; j < NNB; ++j)
+            {
                 dp_store_block<NC>(condT, rbase + 32 * i, 32 * j + c32, hh, [&](int r) { return fmaxf(acc[i][j][r], 0.f); });
+                if (SAVE) save_block(a.y_save, rbase + 32 * i, j, [&](int r) { return fmaxf(acc[i][j][r], 0.f); });
+            }
     }
     __syncthreads();
     const int mblocks = (a.M + 31) / 32;
