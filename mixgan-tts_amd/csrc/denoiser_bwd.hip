@@ -10,6 +10,9 @@
 //   dWo = dout (x) g_l                      dz  = gate'(Wo^T dout)        (EpiGateBwd)
 //   dW3 = dz (x) shift(h_l)                 dh  = W3^T (*) dz             (EpiDhBwd: dx_l = dh + dx_{l+1}/sqrt2)
 #include "denoiser_common.h"
+#include "denoiser_bwd_persist.h"
+#include <atomic>
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------ epilogues
 struct EpiGateBwd {
@@ -234,9 +237,41 @@ extern "C" int mg_denoiser_bwd(const mg_denoiser_dims *d, const float *packed, c
         if (e != hipSuccess) return (int)e;
     }
 
-    // ---- residual layers, top to bottom: data gradients only (2 launches per layer) ------------
+    // ---- residual layers, top to bottom: data gradients only ------------------------------------
     // dout = [dx_l / sqrt2 ; dskip]; slot l+1 of dx_all holds the dx that ENTERS layer l, slot l the one it produces
-    for (int l = NL - 1; l >= 0; --l) {
+    // One persistent launch (denoiser_bwd_persist.h) when the shapes allow; MG_DENOISER_PERSIST=0 keeps the two
+    // generic conv launches per layer.
+    static std::atomic<unsigned> bwd_epoch{0};
+    const char *pe = std::getenv("MG_DENOISER_PERSIST");
+    const int tiles_per_b = mg_cdiv(L, 32);
+    const bool persist = !(pe && pe[0] == '0') && C == RB_C && NL >= 3 && tiles_per_b <= 64;
+    if (persist) {
+        BwdPersistArgs pa;
+        pa.dout = dout;
+        pa.sig = ws + w.sig;
+        pa.tnh = ws + w.tnh;
+        pa.act_stride = w.act_stride;
+        pa.blayers = packed + o.blayers;
+        pa.blayer_stride = o.blayer_stride;
+        pa.bl_woT = o.bl_woT;
+        pa.bl_w3T = o.bl_w3T;
+        pa.dz_all = dz_all;
+        pa.dx_all = dx_all;
+        pa.dh_all = dh_all;
+        pa.gran = reinterpret_cast<dp_u64 *>(bws + bw.gran);
+        pa.sync = reinterpret_cast<unsigned *>(bws + bw.sync);
+        pa.epoch_base = bwd_epoch.fetch_add((unsigned)NL + 1u);
+        pa.B = B;
+        pa.L = L;
+        pa.NL = NL;
+        pa.tiles_per_b = tiles_per_b;
+        const bool vec4 = (L % 4 == 0) && (((uintptr_t)dout & 15) == 0);
+        dim3 grid((unsigned)(tiles_per_b * B));
+        if (vec4) hipLaunchKernelGGL(denoiser_bwd_persist_kernel<true>, grid, dim3(512), 0, st, pa);
+        else hipLaunchKernelGGL(denoiser_bwd_persist_kernel<false>, grid, dim3(512), 0, st, pa);
+        MG_LAUNCH_CHECK();
+    }
+    for (int l = persist ? -1 : NL - 1; l >= 0; --l) {
         const float *bp = packed + o.blayers + (size_t)l * o.blayer_stride;
         const float *sig_l = ws + w.sig + (size_t)l * w.act_stride;
         const float *tnh_l = ws + w.tnh + (size_t)l * w.act_stride;

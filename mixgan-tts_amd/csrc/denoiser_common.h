@@ -163,6 +163,8 @@ struct DenBws {
     // gradient so that the weight / bias gradients of all layers are computed in a handful of grouped launches at
     // the end (0.5 GB at B=8, L=1000 -- 0.2 % of HBM) instead of 5 small launches per layer.
     size_t dout, dz_all, dx_all, dh_all, dy, dx0, scratch, dd_all, dhv_all, ds, dm, da, btop, bbot, total;
+    // single-launch data gradients (denoiser_bwd_persist.h): counters (ZERO at first use) + dz hand-off granules
+    size_t sync, gran;
 };
 
 static inline DenBws den_bws(const mg_denoiser_dims *d, int B, int L)
@@ -205,6 +207,8 @@ static inline DenBws den_bws(const mg_denoiser_dims *d, int B, int L)
     w.ds = take(B * C);
     w.dm = take(B * 4 * C);
     w.da = take(B * 4 * C);
+    w.sync = take(64);
+    w.gran = take(2 * den_persist_tiles(B, L) * 2 * (2 * C) * 2);
     w.total = p;
     return w;
 }

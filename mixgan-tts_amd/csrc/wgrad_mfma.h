@@ -12,6 +12,11 @@
 // sums the splits in a fixed order while it transposes to the [Co, Ci, K] parameter layout.  (The first
 // version combined the partials with fp32 atomics into one [K][Co][Ci] buffer: 8.4 M atomics per launch,
 // 15-30 us of a 60-100 us kernel, a memset in front, and a summation order that changed run to run.)
+//
+// Measured and rejected (round 2): frame-interleaved tiles (stride 68, position (f & 1) * 4 + ((f >> 1) & 3) inside every
+// 8 frames) read with one ds_read_b128 per operand block and 4 k-steps -- 4 LDS reads per 16 MFMAs instead of 16.  The
+// reads were conflict-free, but the staging stores of that layout are 4-way bank-conflicted (2-way here), and they sit
+// between the two barriers of a chunk where nothing overlaps them: 253-259 us per launch against 221 us.
 #pragma once
 #include "common.h"
 

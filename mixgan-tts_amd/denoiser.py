@@ -244,7 +244,8 @@ class Denoiser(nn.Module):
         bws = self._bws.get(k)
         if bws is None:
             # transient scratch of this call only (stream-ordered), so eviction is always safe
-            bws = torch.empty(L_.mg_denoiser_bwd_workspace_floats(ctypes.byref(d), B, L), device=dev)
+            # zero-filled once: the single-launch data-gradient kernel keeps its counters in here
+            bws = torch.zeros(L_.mg_denoiser_bwd_workspace_floats(ctypes.byref(d), B, L), device=dev)
             self._bws[k] = bws
             while len(self._bws) > 4:
                 self._bws.popitem(last=False)
