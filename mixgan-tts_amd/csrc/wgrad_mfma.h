@@ -21,8 +21,8 @@
 #include "common.h"
 
 #define WG_FT 64
-#define WG_RS 65
-#define WG_TILE (128 * WG_RS)
+#define WG_RSA 65   // odd strides: the 32 lanes of a fragment read (32 rows, one column) hit 32 banks
+#define WG_RSB 73
 
 struct WgradArgs {
     const float *dy;    // [B, Co, Ldy] (batch stride dy_bs, row stride Ldy)
@@ -44,7 +44,11 @@ struct WgradArgs {
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a)
 {
-    __shared__ float lds[2][WG_TILE];  // [A|B], single-buffered (66.5 KB -> two workgroups per CU)
+    // [A: 128 rows x 64 frames, stride 65 | B: 128 rows x 72 frames, stride 73], single-buffered (70.7 KB -> two
+    // workgroups per CU).  The B tile holds the ALIGNED 72-frame window that contains the tap-shifted 64 frames; the
+    // shift is applied when the fragments are read (an address offset), not when the tile is written.
+    __shared__ float lds[128 * WG_RSA + 128 * WG_RSB];
+    float *ldsA = lds, *ldsB = lds + 128 * WG_RSA;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -65,35 +69,53 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    constexpr int NSA = VEC ? 8 : 32, NSB = VEC ? 9 : 32;
     f32x4 va[VEC ? 8 : 1], vb[VEC ? 9 : 1];
     float sa[VEC ? 1 : 8], sb[VEC ? 1 : 8];  // scalar path stages in 4 batches of 8 (no prefetch, no spill)
     const int shift = tap - a.pad;
-    const int shift4 = shift & ~3, rsh = shift & 3;  // aligned window start and residual (VEC)
-    (void)NSA; (void)NSB; (void)shift4; (void)rsh;
+    const int shift4 = shift & ~3, rsh = VEC ? (shift & 3) : 0;  // aligned window start and residual (VEC)
+    // Everything about a staging element that does not depend on the chunk is computed ONCE here: the staging code
+    // used to redo ~30 integer instructions per element per chunk (divisions by 17, clamps, a branch per scattered
+    // store), as many issue cycles as the chunk's MFMAs -- which is what held this kernel at half of the MFMA peak.
+    const int c4A = tid & 15;
+    int gA[VEC ? 8 : 1], gB[VEC ? 9 : 1], lB[VEC ? 9 : 1], c4B[VEC ? 9 : 1];
+    unsigned okA = 0, okB = 0;   // bit k: the element's row exists (and, for B, the element is inside the 128 x 18 window)
+    if (VEC) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int row = (tid >> 4) + 16 * k;
+            gA[k] = min(co0 + row, a.Co - 1) * a.Ldy;
+            if (co0 + row < a.Co) okA |= 1u << k;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int idx = tid + k * 256;   // 128 rows x 18 float4 = 2304
+            const int row = min(idx / 18, 127), c4 = idx - (idx / 18) * 18;
+            gB[k] = min(ci0 + row, a.Ci - 1) * a.Lx;
+            lB[k] = row * WG_RSB + 4 * c4;
+            c4B[k] = c4;
+            if (idx < 128 * 18 && ci0 + row < a.Ci) okB |= 1u << k;
+        }
+    }
     auto load_stage = [&](int chunk) {
         const int b = chunk / a.chunks_per_b;
         const int f0 = (chunk - b * a.chunks_per_b) * WG_FT;
         const float *dyb = a.dy + (size_t)grp * a.dy_gs + (size_t)b * a.dy_bs;
         const float *xb = a.x + (size_t)grp * a.x_gs + (size_t)b * a.x_bs;
         if (VEC) {
+            const int f = f0 + 4 * c4A;
+            const bool fok = f < a.Ldy;
+            const int fcl = min(f, a.Ldy - 4);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int idx = tid + k * 256;  // 128 rows x 16 float4
-                const int row = idx >> 4, c4 = idx & 15;
-                const int co = co0 + row, f = f0 + 4 * c4;
-                const bool ok = co < a.Co && f < a.Ldy;
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(dyb + (size_t)min(co, a.Co - 1) * a.Ldy + min(f, a.Ldy - 4));
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(dyb + gA[k] + fcl);
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                va[k] = ok ? v : z;
+                va[k] = (fok && ((okA >> k) & 1u)) ? v : z;
             }
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                const int idx = tid + k * 256;  // 128 rows x 17 float4 = 2176
-                const int row = idx / 17, c4 = idx - row * 17;
-                const int ci = ci0 + row, xf = f0 + shift4 + 4 * c4;
-                const bool ok = idx < 128 * 17 && ci < a.Ci && xf >= 0 && xf < a.Lx;
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(xb + (size_t)min(ci, a.Ci - 1) * a.Lx + min(max(xf, 0), a.Lx - 4));
+                const int xf = f0 + shift4 + 4 * c4B[k];
+                const bool ok = ((okB >> k) & 1u) && xf >= 0 && xf < a.Lx;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(xb + gB[k] + min(max(xf, 0), a.Lx - 4));
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 vb[k] = ok ? v : z;
             }
@@ -125,31 +147,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a)
                 for (int k = 0; k < 8; ++k) {
                     const int idx = tid + (kb + k) * 256;
                     const int row = idx >> 6, c = idx & 63;
-                    lds[0][row * WG_RS + c] = sa[k];
-                    lds[1][row * WG_RS + c] = sb[k];
+                    ldsA[row * WG_RSA + c] = sa[k];
+                    ldsB[row * WG_RSB + c] = sb[k];
                 }
             }
         }
     };
     auto store_stage = [&]() {
         if (VEC) {
+            float *dA = ldsA + (tid >> 4) * WG_RSA + 4 * c4A;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int idx = tid + k * 256;
-                const int row = idx >> 4, c4 = idx & 15;
+            for (int k = 0; k < 8; ++k)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) lds[0][row * WG_RS + 4 * c4 + j] = va[k][j];
-            }
+                for (int j = 0; j < 4; ++j) dA[k * 16 * WG_RSA + j] = va[k][j];   // immediate offsets off one base
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                const int idx = tid + k * 256;
-                const int row = idx / 17, c4 = idx - row * 17;
-                if (idx < 128 * 17) {
+                if (k < 8 || tid + 8 * 256 < 128 * 18) {   // k = 8: only the first 256 of the 2304 window elements
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int c = 4 * c4 + j - rsh;  // tile column of window element (4 c4 + j)
-                        if (c >= 0 && c < WG_FT) lds[1][row * WG_RS + c] = vb[k][j];
-                    }
+                    for (int j = 0; j < 4; ++j) ldsB[lB[k] + j] = vb[k][j];
                 }
             }
         }
@@ -161,15 +176,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a)
         store_stage();
     }
     __syncthreads();
-    const float *A = lds[0] + (wm * 64 + c32) * WG_RS + hh;
-    const float *Bt = lds[1] + (wn * 64 + c32) * WG_RS + hh;
+    const float *A = ldsA + (wm * 64 + c32) * WG_RSA + hh;
+    const float *Bt = ldsB + (wn * 64 + c32) * WG_RSB + hh + rsh;
     for (; chunk < a.nchunks; chunk += a.nsplit) {
         const bool more = chunk + a.nsplit < a.nchunks;
         if (VEC && more) load_stage(chunk + a.nsplit);  // global loads fly behind the MFMAs below
 #pragma unroll 8
         for (int s = 0; s < WG_FT / 2; ++s) {
-            const float a0 = A[2 * s], a1 = A[32 * WG_RS + 2 * s];
-            const float b0 = Bt[2 * s], b1 = Bt[32 * WG_RS + 2 * s];
+            const float a0 = A[2 * s], a1 = A[32 * WG_RSA + 2 * s];
+            const float b0 = Bt[2 * s], b1 = Bt[32 * WG_RSB + 2 * s];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
