@@ -54,6 +54,8 @@ const char *mg_error_string(int code);
 #define MG_PACK_GATE 1   /* rows interleaved so that channel c and c+Co/2 share a lane (GLU gate) */
 #define MG_PACK_DGRAD 2  /* transposed + tap-flipped: the data-gradient convolution (stride 1) */
 #define MG_PACK_TPOSE 3  /* internal to mg_conv_transpose_pack (polyphase ConvTranspose1d); rejected by mg_conv_pack */
+#define MG_PACK_PLAIN16 4 /* as PLAIN, fragments of v_mfma_f32_16x16x4_f32 (16-row blocks, 16-channel k-groups); K <= 3 */
+#define MG_PACK_GATE16 5  /* as GATE for the 16x16x4 form: per 32 channels two gate 16-row blocks, then two filter ones */
 
 /* Number of floats of the packed form of a [Co, Ci, K] weight. */
 size_t mg_conv_packed_floats(int Co, int Ci, int K, int mode);
@@ -182,9 +184,11 @@ typedef struct {
 /* flags for mg_denoiser_packed_floats / mg_denoiser_pack */
 #define MG_DEN_BACKWARD 1 /* also pack the transposed (data-gradient) forms mg_denoiser_bwd consumes */
 #define MG_DEN_SPLIT 2    /* also pack hi/lo bf16 pairs for the split-precision forward */
+#define MG_DEN_P16 4      /* also pack the 16x16x4-MFMA forms: the 16-frame tile width of the single-launch forward */
 /* flags for mg_denoiser_fwd's `mode` */
 #define MG_FWD_SAVE 1     /* keep per-layer activations for mg_denoiser_bwd (fp32 path only) */
 #define MG_FWD_SPLIT 2    /* residual-layer GEMMs as 3-term bf16-split MFMA products (fp32-grade, ~1e-5) */
+#define MG_FWD_P16 4      /* `packed` was built with MG_DEN_P16: small launches may use the 16-frame tile width */
 size_t mg_denoiser_packed_floats(const mg_denoiser_dims *d, int flags);
 /* freq: the C/2 step-embedding frequencies exp(-i ln(1e4)/(C/2-1)) (model/blocks.py:909-910),
  * computed by the host exactly as the reference does and cached in the packed blob. */

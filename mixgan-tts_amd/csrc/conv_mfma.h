@@ -55,17 +55,26 @@ __device__ __forceinline__ float mg_pack_element(const float *__restrict__ w, co
     const int rem = q - chunk * qc;
     const int tap = rem / (d.CK / 8);
     const int g = rem - tap * (d.CK / 8);
-    const int ci = chunk * d.CK + g * 8 + 2 * e + (lane >> 5);
-    const int r = lane & 31;
+    int ci = chunk * d.CK + g * 8 + 2 * e + (lane >> 5);
+    int r = lane & 31;
     const int Co = d.Co, Ci = d.Ci, K = d.K;
     float v = 0.f;
-    if (d.mode == MG_PACK_PLAIN) {
+    int mode = d.mode;
+    if (mode == MG_PACK_PLAIN16 || mode == MG_PACK_GATE16) {
+        // v_mfma_f32_16x16x4_f32 fragments (A[row = lane & 15][k = lane >> 4]) in the same container: the 256 floats of
+        // (32-row block mb, 8-channel group g) hold 16-row block (g & 1) of mb for the 16-channel group (g >> 1) of
+        // the chunk; element e of a lane is k-step e: channel 16 (g >> 1) + 4 e + (lane >> 4)
+        r = 16 * (g & 1) + (lane & 15);
+        ci = chunk * d.CK + 16 * (g >> 1) + 4 * e + (lane >> 4);
+        mode = mode == MG_PACK_PLAIN16 ? MG_PACK_PLAIN : MG_PACK_GATE;
+    }
+    if (mode == MG_PACK_PLAIN) {
         const int row = mb * 32 + r;
         if (row < Co && ci < Ci) v = w[((size_t)row * Ci + ci) * K + tap];
-    } else if (d.mode == MG_PACK_GATE) {
+    } else if (mode == MG_PACK_GATE) {
         const int half = mb & 1, rr = (mb >> 1) * 32 + r;
         if (rr < Co / 2 && ci < Ci) v = w[((size_t)(half * (Co / 2) + rr) * Ci + ci) * K + tap];
-    } else if (d.mode == MG_PACK_TPOSE) {
+    } else if (mode == MG_PACK_TPOSE) {
         // ConvTranspose1d weight [Ci, Co', 2u] (stride u, padding u/2) as the 3-tap polyphase GEMM:
         // row = co*u + phase; output u*m + phase reads x[m + c0] with tap rho and x[m + c0 - 1] with
         // tap rho + u, where rho = (phase + u/2) % u, c0 = (phase + u/2) / u; here `Co` = Co' * u.
@@ -490,11 +499,12 @@ static inline int pack_dims(int Co, int Ci, int K, int mode, int *Mrows, int *Ki
 {
     if (Co <= 0 || Ci <= 0 || !(K == 1 || K == 3 || K == 4 || K == 5 || K == 7 || K == 9 || K == 11 || K == 16))
         return MG_ERR_SHAPE;
-    if (mode == MG_PACK_PLAIN) {
+    if ((mode == MG_PACK_PLAIN16 || mode == MG_PACK_GATE16) && K > 3) return MG_ERR_SHAPE;   // 32-channel chunks only
+    if (mode == MG_PACK_PLAIN || mode == MG_PACK_PLAIN16) {
         *Mrows = Co;
         *Kin = Ci;
         *MB = mg_conv_mblocks(Co);
-    } else if (mode == MG_PACK_GATE) {
+    } else if (mode == MG_PACK_GATE || mode == MG_PACK_GATE16) {
         if (Co % 2) return MG_ERR_SHAPE;
         *Mrows = Co;
         *Kin = Ci;

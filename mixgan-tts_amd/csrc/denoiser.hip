@@ -13,6 +13,7 @@
 #include "resblock_split.h"
 #include "pointwise_fused.h"
 #include "denoiser_persist.h"
+#include "denoiser_persist16.h"
 #include <atomic>
 #include <cstdlib>
 
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void pack_table_kernel(const PackJob *__restri
     }
 }
 
-#define MG_DEN_MAX_JOBS 512
+#define MG_DEN_MAX_JOBS 768
 static_assert(sizeof(PackJob) <= 96, "den_layout reserves 96 bytes per pack job");
 
 extern "C" int mg_denoiser_pack(const mg_denoiser_dims *d, const float *const *w, const float *freq, float *packed,
@@ -273,6 +274,19 @@ extern "C" int mg_denoiser_pack(const mg_denoiser_dims *d, const float *const *w
             pack(lw[3], o.wc_allT, C, H, 1, MG_PACK_DGRAD, l * (C / 8), Qtot);
             pack(lw[0], bp + o.bl_w3T, 2 * C, C, 3, MG_PACK_DGRAD);
             pack(lw[5], bp + o.bl_woT, 2 * C, C, 1, MG_PACK_DGRAD);
+        }
+    }
+    if (flags & MG_DEN_P16) {
+        if (C != RB_C || H != RB_C) return MG_ERR_SHAPE;
+        pack(w[0], o.in_w16, C, M, 1, MG_PACK_PLAIN16);
+        pack(w[4], o.skip_w16, C, C, 1, MG_PACK_PLAIN16);
+        pack(w[6], o.out_w16, M, C, 1, MG_PACK_PLAIN16);
+        for (int l = 0; l < d->n_layers; ++l) {
+            const float *const *lw = w + MG_DEN_HEAD_PTRS + (size_t)l * MG_DEN_LAYER_PTRS;
+            const size_t pp = o.p16layers + (size_t)l * o.p16layer_stride;
+            pack(lw[3], pp + o.p_wc, C, H, 1, MG_PACK_PLAIN16);
+            pack(lw[0], pp + o.p_w3, 2 * C, C, 3, MG_PACK_GATE16);
+            pack(lw[5], pp + o.p_wo, 2 * C, C, 1, MG_PACK_PLAIN16);
         }
     }
     if (rc != MG_OK) return rc;
@@ -540,6 +554,7 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
 {
     const int save = mode & MG_FWD_SAVE;
     const int split = mode & MG_FWD_SPLIT;
+    const int has_p16 = mode & MG_FWD_P16;
     if (split && save) return MG_ERR_ARG;  // the backward consumes fp32 activations
     MG_TRY(den_check(d));
     if (!packed || !x_t || !t || !cond || !out || !ws) return MG_ERR_ARG;
@@ -549,7 +564,7 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
     if (ws_floats < w.total) return MG_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int C = d->channels, H = d->cond_channels, M = d->mel_bins, NL = d->n_layers;
-    const DenLayout o = den_layout(d, split ? MG_DEN_SPLIT : 0);
+    const DenLayout o = den_layout(d, (split ? MG_DEN_SPLIT : 0) | (has_p16 ? MG_DEN_P16 : 0));
     const float *lay0 = packed + o.layers;
 
     // step embedding -> MLP -> per-layer projections (model/modules.py:433-434, blocks.py:1159)
@@ -573,11 +588,15 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
     const bool no_persist = pe && pe[0] == '0';
     // tile width: 64 frames (8 waves, one workgroup per CU, weights streamed once per 64 frames) when that still gives
     // more than 128 workgroups, else 32 frames (4 waves, two per CU: twice the workgroups for small launches)
+    // ... and 16 frames (v_mfma_f32_16x16x4_f32, denoiser_persist16.h) when even the 32-frame tiling leaves half the
+    // CUs idle: single utterances, the configs[0] shape.  Inference only; needs the 16-row packs (MG_FWD_P16).
     int nt = (long)mg_cdiv(L, 64) * B > 128 ? 64 : 32;
+    if (nt == 32 && has_p16 && !save && (long)mg_cdiv(L, 32) * B <= 128) nt = 16;
     if (const char *ne = std::getenv("MG_PERSIST_NT")) {   // tests pin each width
         const int f = std::atoi(ne);
-        if (f == 32 || f == 64) nt = f;
+        if (f == 32 || f == 64 || (f == 16 && has_p16 && !save)) nt = f;
     }
+    if (nt == 16 && mg_cdiv(L, 16) > 128) nt = 32;
     const int tiles_per_b = mg_cdiv(L, nt);
     const int chain_cap = nt == 64 ? 64 : 128;   // a quarter of the 256 / 512 slots
     if (fused && !no_persist && !split && M <= 96 && NL >= 3 && tiles_per_b <= chain_cap) {
@@ -598,6 +617,16 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
         a.skip_b = packed + o.skip_b;
         a.out_w = packed + o.out_w;
         a.out_b = packed + o.out_b;
+        a.p16layers = packed + o.p16layers;
+        a.p16layer_stride = o.p16layer_stride;
+        a.p_wc = o.p_wc;
+        a.p_w3 = o.p_w3;
+        a.p_wo = o.p_wo;
+        if (nt == 16) {   // the 16x16x4 forms of the head / tail projections
+            a.in_w = packed + o.in_w16;
+            a.skip_w = packed + o.skip_w16;
+            a.out_w = packed + o.out_w16;
+        }
         a.hvec = ws + w.hvec;
         a.dvec = ws + w.dvec;
         a.out = out;
@@ -637,7 +666,10 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
         dim3 grid((unsigned)(tiles_per_b * B));
         prof_mark(st, 0);
 #define MG_DP_LAUNCH(NT, V, T, S) hipLaunchKernelGGL((denoiser_persist_kernel<NT, V, T, S>), grid, dim3(NT * 8), 0, st, a)
-        if (nt == 64) {
+        if (nt == 16) {
+            if (vec4) hipLaunchKernelGGL(denoiser_persist16_kernel<true>, grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(denoiser_persist16_kernel<false>, grid, dim3(256), 0, st, a);
+        } else if (nt == 64) {
             if (save) {
                 if (vec4) MG_DP_LAUNCH(64, true, false, true);
                 else MG_DP_LAUNCH(64, false, false, true);

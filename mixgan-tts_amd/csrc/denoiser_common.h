@@ -14,6 +14,8 @@ struct DenLayout {
     size_t bl_w3T, bl_woT;
     // split-bf16 section (resblock_split.h), present when flags & MG_DEN_SPLIT
     size_t slayers, slayer_stride, sl_wc, sl_w3, sl_wo;
+    // 16x16x4-MFMA packs (denoiser_persist16.h), present when flags & MG_DEN_P16
+    size_t in_w16, skip_w16, out_w16, p16layers, p16layer_stride, p_wc, p_w3, p_wo;
     size_t jobs;   // scratch slice for the pack job table (mg_denoiser_pack)
     size_t total;
 };
@@ -94,10 +96,28 @@ static inline DenLayout den_layout(const mg_denoiser_dims *d, int flags)
         o.slayer_stride = r;
         p += r * NL;
     }
-    // reserved for the job table of mg_denoiser_pack (512 entries x 96 B, 16-byte aligned)
+    o.in_w16 = o.skip_w16 = o.out_w16 = o.p16layers = o.p16layer_stride = o.p_wc = o.p_w3 = o.p_wo = 0;
+    if (flags & MG_DEN_P16) {
+        o.in_w16 = take(mg_conv_packed_floats(C, M, 1, MG_PACK_PLAIN16));
+        o.skip_w16 = take(mg_conv_packed_floats(C, C, 1, MG_PACK_PLAIN16));
+        o.out_w16 = take(mg_conv_packed_floats(M, C, 1, MG_PACK_PLAIN16));
+        o.p16layers = p;
+        size_t r = 0;
+        auto ptake = [&](size_t n) {
+            size_t at = r;
+            r += mg_align_up(n, 64);
+            return at;
+        };
+        o.p_wc = ptake(mg_conv_packed_floats(C, H, 1, MG_PACK_PLAIN16));
+        o.p_w3 = ptake(mg_conv_packed_floats(2 * C, C, 3, MG_PACK_GATE16));
+        o.p_wo = ptake(mg_conv_packed_floats(2 * C, C, 1, MG_PACK_PLAIN16));
+        o.p16layer_stride = r;
+        p += r * NL;
+    }
+    // reserved for the job table of mg_denoiser_pack (768 entries x 96 B, 16-byte aligned)
     p = mg_align_up(p, 64);
     o.jobs = p;
-    p += 512 * 96 / 4;
+    p += 768 * 96 / 4;
     o.total = p;
     return o;
 }
@@ -121,7 +141,7 @@ struct DenWs {
 };
 
 // 32-frame tiles of the single-launch forward
-static inline size_t den_persist_tiles(int B, int L) { return (size_t)B * ((L + 31) / 32); }
+static inline size_t den_persist_tiles(int B, int L) { return (size_t)B * ((L + 15) / 16); }
 
 static inline DenWs den_ws(const mg_denoiser_dims *d, int B, int L, int save)
 {

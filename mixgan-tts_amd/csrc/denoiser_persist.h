@@ -42,6 +42,8 @@ struct PersistArgs {
     const float *in_w, *in_b;             // packed PLAIN [256 rows, K = 96], [256]
     const float *layers;                  // first layer record
     size_t layer_stride, l_wc, l_w3, l_wo, l_bc, l_b3, l_bo;
+    const float *p16layers;               // 16-row packs (denoiser_persist16.h): first layer record, stride, offsets
+    size_t p16layer_stride, p_wc, p_w3, p_wo;
     const float *skip_w, *skip_b, *out_w, *out_b;
     const float *hvec, *dvec;             // [NL][B][256]
     float *out;                           // [B, M, L]  predicted x_0 (pre-clamp), or x_{t-1} when post != 0

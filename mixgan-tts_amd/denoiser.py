@@ -73,6 +73,10 @@ class Denoiser(nn.Module):
             raise ValueError("Denoiser.precision must be 'fp32' or 'bf16x3'")
         prev = self._packed_key[0] if self._packed_key is not None else 0
         with_backward = (1 if with_backward else 0) | (prev & 1) | (2 if self.precision == "bf16x3" else 0) | (prev & 2)
+        # the 16x16x4-MFMA packs (16-frame tiles for single utterances / small batches): inference only -- a module
+        # that trains repacks every step and never launches that width
+        if not (with_backward & 1) and self._dims.channels == 256 and self._dims.cond_channels == 256:
+            with_backward |= 4
         key = (with_backward,) + tuple((p.data_ptr(), p._version) for p in table if p is not None)
         if self._packed is None or key != self._packed_key:
             L = _lib.lib()
@@ -131,6 +135,8 @@ class Denoiser(nn.Module):
         if out is None:
             out = torch.empty_like(x_t)
         mode = 1 if save else (2 if self.precision == "bf16x3" else 0)
+        if self._packed_key is not None and (self._packed_key[0] & 4) and packed is self._packed:
+            mode |= 4      # MG_FWD_P16: the blob carries the 16-row packs
         check(_lib.lib().mg_denoiser_fwd(ctypes.byref(self._dims), fptr(packed), fptr(x_t), iptr(t, torch.int64),
                                          fptr(cond), fptr(spk, not self.multi_speaker), fptr(out), fptr(ws),
                                          ws.numel(), B, L, mode, stream_ptr()))
@@ -153,6 +159,8 @@ class Denoiser(nn.Module):
         if getattr(self, "_rng_seed", None) is None:
             self._rng_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         mode = 2 if self.precision == "bf16x3" else 0
+        if self._packed_key is not None and (self._packed_key[0] & 4) and packed is self._packed:
+            mode |= 4
         check(_lib.lib().mg_denoiser_psample(
             ctypes.byref(self._dims), fptr(packed), fptr(x_t), iptr(t, torch.int64), fptr(cond),
             fptr(spk, not self.multi_speaker), fptr(coef1), fptr(coef2), fptr(logvar), coef1.numel(), fptr(noise, True),
