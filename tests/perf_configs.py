@@ -43,7 +43,8 @@ def main():
     stats = write_stats(d, [-11.5] * 80, [2.0] * 80, n_speakers=218)
     out = []
     # cfg1-shape / cfg2-shape inference steps, eager vs graph
-    for name, model, T, B, L in (("cfg1 naive T=4 B=4 L=256", "naive", 4, 4, 256),
+    for name, model, T, B, L in (("one utterance naive T=4 B=1 L=1000", "naive", 4, 1, 1000),
+                                 ("cfg1 naive T=4 B=4 L=256", "naive", 4, 4, 256),
                                  ("cfg2 naive T=4 B=16 L=1000", "naive", 4, 16, 1000),
                                  ("cfg3 shallow T=100 B=32 L=1000", "shallow", 100, 32, 1000)):
         gd = mg.GaussianDiffusion(*hot_path_configs(model, T, stats_dir=stats))
