@@ -10,21 +10,28 @@
 //         scalars (one cross-half shuffle) -- no cross-lane reductions;
 //   O^T += V P^T reuses that accumulator directly as the MFMA B operand: k-step (a,b) takes key
 //         8a + 4h + b for lane half h, which is exactly register 4a+b of every lane, and V is read
-//         from LDS with the same key permutation (odd row stride 65 -> conflict-free).
+//         from LDS with the same key permutation.
 #include "common.h"
 
 #define AT_D 128   // head dim (d_k = d_v = decoder_hidden / decoder_head = 128)
 #define AT_KT 64   // keys per LDS tile
-#define AT_RS 65   // LDS row stride (odd)
+#define AT_RSK 132 // K tile [key][d], d interleaved inside every 8 (position (d & 1) * 4 + ((d >> 1) & 3)): the fragments of
+                   // four k-steps (d = 2s + h) of a lane are 16 contiguous bytes -> one ds_read_b128 per 4 MFMAs
+#define AT_RSV 68  // V tile [d][key]: the four keys 8a + 4h + {0..3} of PV k-steps 4a .. 4a+3 are contiguous -> ds_read_b128
+                   // (both strides = 4 mod 64 words: the 16-lane groups of a b128 read land on 16 distinct 4-bank slots)
 #define AT_NEG (-1.0e30f)
 
+// Round 2: one LDS read per FOUR MFMAs (was one ds_read_b32 per MFMA), the next key tile's global loads in flight behind
+// the current tile's MFMAs (was: loaded after the barrier, fully exposed), the key mask as one ballot word per 32 keys
+// (was 16 LDS reads per block), the accumulator rescale skipped while the running maximum does not move.
+template <bool VEC>
 __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const float *__restrict__ qkv,
                                                                const uint8_t *__restrict__ key_pad,
                                                                float *__restrict__ out, int L, int n_head, float scale)
 {
-    __shared__ float Kt[AT_D * AT_RS];
-    __shared__ float Vt[AT_D * AT_RS];
-    __shared__ float kmask[AT_KT];
+    __shared__ __attribute__((aligned(16))) float Kt[AT_KT * AT_RSK];
+    __shared__ __attribute__((aligned(16))) float Vt[AT_D * AT_RSV];
+    __shared__ unsigned kmask[2];   // bit j of word kb: key kb*32 + j of the tile is masked
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, r = lane & 31;
@@ -49,41 +56,85 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const float *__re
         for (int j = 0; j < 16; ++j) O[i][j] = 0.f;
     float m_run = AT_NEG, l_run = 0.f;
 
+    // staging roles.  K: thread <-> (key, 32 channels): 32 coalesced row reads, 8 ds_write_b128 into the key's row.
+    //                 V: thread <-> (channel, 4 keys) x 8: one 16-byte read, one ds_write_b128.
+    const int skey = tid & 63, sdq = tid >> 6;
+    float kreg[32];
+    f32x4 vreg[8];
+    bool kmasked = false;
+    auto load_tile = [&](int kt0) {
+        const int key = kt0 + skey;
+        const int kc = min(key, L - 1);
+        const float *kp = K + (size_t)(32 * sdq) * L + kc;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) kreg[i] = kp[(size_t)i * L];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int d = (tid >> 4) + 16 * k, k4 = tid & 15;
+            const int f0 = kt0 + 4 * k4;
+            if (VEC) {
+                vreg[k] = *reinterpret_cast<const f32x4 *>(V + (size_t)d * L + min(f0, L - 4));
+                if (f0 >= L) vreg[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = V[(size_t)d * L + min(f0 + e, L - 1)];
+                    vreg[k][e] = f0 + e < L ? v : 0.f;
+                }
+            }
+        }
+        if (tid < AT_KT) kmasked = key >= L || (key_pad && key_pad[(size_t)b * L + kc]);
+        if (key >= L) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) kreg[i] = 0.f;
+        }
+    };
+    auto store_tile = [&]() {
+        float *kd = Kt + skey * AT_RSK + 32 * sdq;
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+            const f32x4 even = {kreg[8 * sg], kreg[8 * sg + 2], kreg[8 * sg + 4], kreg[8 * sg + 6]};
+            const f32x4 odd = {kreg[8 * sg + 1], kreg[8 * sg + 3], kreg[8 * sg + 5], kreg[8 * sg + 7]};
+            *reinterpret_cast<f32x4 *>(kd + 8 * sg) = even;
+            *reinterpret_cast<f32x4 *>(kd + 8 * sg + 4) = odd;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            *reinterpret_cast<f32x4 *>(Vt + ((tid >> 4) + 16 * k) * AT_RSV + 4 * (tid & 15)) = vreg[k];
+        if (tid < AT_KT) {
+            const unsigned long long bal = __ballot(kmasked);   // wave 0: lane j <-> key j of the tile
+            if (tid == 0) {
+                kmask[0] = (unsigned)bal;
+                kmask[1] = (unsigned)(bal >> 32);
+            }
+        }
+    };
+
+    load_tile(0);
     for (int kt0 = 0; kt0 < L; kt0 += AT_KT) {
         __syncthreads();  // previous tile fully consumed
-#pragma unroll
-        for (int k = 0; k < (AT_D * AT_KT) / 256; ++k) {
-            const int idx = tid + k * 256;
-            const int d = idx >> 6, j = idx & 63;
-            const int key = kt0 + j;
-            const bool ok = key < L;
-            const size_t off = (size_t)d * L + min(key, L - 1);
-            const float kv = K[off], vv = V[off];
-            Kt[d * AT_RS + j] = ok ? kv : 0.f;
-            Vt[d * AT_RS + j] = ok ? vv : 0.f;
-        }
-        if (tid < AT_KT) {
-            const int key = kt0 + tid;
-            const bool masked = key >= L || (key_pad && key_pad[(size_t)b * L + min(key, L - 1)]);
-            kmask[tid] = masked ? 1.f : 0.f;
-        }
+        store_tile();
         __syncthreads();
+        if (kt0 + AT_KT < L) load_tile(kt0 + AT_KT);   // flies behind the 256 MFMAs below
 #pragma unroll
         for (int kb = 0; kb < AT_KT / 32; ++kb) {
             f32x16 S;
 #pragma unroll
             for (int j = 0; j < 16; ++j) S[j] = 0.f;
-            const float *Kp = Kt + hh * AT_RS + kb * 32 + r;
+            const float *Kp = Kt + (kb * 32 + r) * AT_RSK + 4 * hh;
 #pragma unroll
-            for (int s = 0; s < AT_D / 2; ++s)
-                S = __builtin_amdgcn_mfma_f32_32x32x2f32(Kp[(2 * s) * AT_RS], qf[s], S, 0, 0, 0);
+            for (int sg = 0; sg < AT_D / 8; ++sg) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(Kp + 8 * sg);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], qf[4 * sg + e], S, 0, 0, 0);
+            }
             // S[p] = score(key = kb*32 + 8(p>>2) + 4h + (p&3), query = r)
-            float mk[16];
+            const unsigned mw = kmask[kb] >> (4 * hh);
             float mx = AT_NEG;
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
-                mk[p] = kmask[kb * 32 + 8 * (p >> 2) + 4 * hh + (p & 3)];
-                const float v = mk[p] != 0.f ? AT_NEG : S[p];
+                const bool masked = (mw >> (8 * (p >> 2) + (p & 3))) & 1u;
+                const float v = masked ? AT_NEG : S[p];
                 S[p] = v;
                 mx = fmaxf(mx, v);
             }
@@ -93,25 +144,32 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const float *__re
             float ps = 0.f;
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
-                const float e = mk[p] != 0.f ? 0.f : __expf(S[p] - m_new);
+                const bool masked = (mw >> (8 * (p >> 2) + (p & 3))) & 1u;
+                const float e = masked ? 0.f : __expf(S[p] - m_new);
                 S[p] = e;
                 ps += e;
             }
             ps += __shfl_xor(ps, 32, 64);
             l_run = l_run * corr + ps;
-            m_run = m_new;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 16; ++j) O[i][j] *= corr;
-            // O^T[d][query] += V[d][key] P^T[key][query]; k-step p <-> key 8(p>>2) + 4h + (p&3)
-            const float *Vp = Vt + r * AT_RS + kb * 32 + 4 * hh;
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const int kc = 8 * (p >> 2) + (p & 3);
+            if (__any(m_new != m_run)) {   // wave-uniform: once the running maxima have settled this is skipped
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    O[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vp[(i * 32) * AT_RS + kc], S[p], O[i], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) O[i][j] *= corr;
+            }
+            m_run = m_new;
+            // O^T[d][query] += V[d][key] P^T[key][query]; k-step p <-> key 8(p>>2) + 4h + (p&3)
+            const float *Vp = Vt + r * AT_RSV + kb * 32 + 4 * hh;
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) {
+                f32x4 va[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) va[i] = *reinterpret_cast<const f32x4 *>(Vp + (i * 32) * AT_RSV + 8 * aa);
+#pragma unroll
+                for (int bq = 0; bq < 4; ++bq)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        O[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[i][bq], S[4 * aa + bq], O[i], 0, 0, 0);
             }
         }
     }
@@ -142,17 +200,21 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const float *__re
 typedef _Float16 mg_half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 mg_half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 mg_half2 __attribute__((ext_vector_type(2)));
-#define AH_KRS 132   // halves per key row of Kt (66 dwords: 2-way write conflicts, 8-byte aligned reads)
-#define AH_VRS 72    // halves per dv row of Vt
+#define AH_KRS 136   // halves per key row of Kt (272 B: 16-byte aligned rows -> the 8 halves of a fragment are one ds_read_b128)
+#define AH_VRS 72    // halves per dv row of Vt; inside every 16 keys, key k sits at position 8 ((k >> 2) & 1) + 4 (k >> 3) + (k & 3):
+                     // the 8 keys of a PV fragment (16t + 8 (j >> 2) + 4h + (j & 3)) are then contiguous -> one ds_read_b128
 
+// Round 2: as the fp32 kernel -- the next key tile's global loads fly behind the current tile's work, fragments are single
+// 16-byte LDS reads, the key mask is a ballot word, the accumulator rescale is skipped while the running maximum rests.
+template <bool VEC>
 __global__ __launch_bounds__(256, 2) void attention_fwd_f16_kernel(const float *__restrict__ qkv,
                                                                    const uint8_t *__restrict__ key_pad,
                                                                    float *__restrict__ out, int L, int n_head,
                                                                    float scale)
 {
     __shared__ __attribute__((aligned(16))) _Float16 Kt[AT_KT * AH_KRS];   // [key][d]
-    __shared__ __attribute__((aligned(16))) _Float16 Vt[AT_D * AH_VRS];    // [dv][key]
-    __shared__ float kmask[AT_KT];
+    __shared__ __attribute__((aligned(16))) _Float16 Vt[AT_D * AH_VRS];    // [dv][key, permuted inside 16]
+    __shared__ unsigned kmask[2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, r = lane & 31;
@@ -178,41 +240,71 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_f16_kernel(const float *
         for (int j = 0; j < 16; ++j) O[i][j] = 0.f;
     float m_run = AT_NEG, l_run = 0.f;
 
-    for (int kt0 = 0; kt0 < L; kt0 += AT_KT) {
-        __syncthreads();  // previous tile fully consumed
-        // K: thread <-> (channel pair, key): two coalesced row reads, one 4-byte LDS write into the key's row
+    const int skey = tid & 63, sdq = tid >> 6;
+    float kreg[32];
+    f32x4 vreg[8];
+    bool kmasked = false;
+    auto load_tile = [&](int kt0) {
+        const int key = kt0 + skey;
+        const int kc = min(key, L - 1);
+        const float *kp = K + (size_t)(32 * sdq) * L + kc;
 #pragma unroll
-        for (int k = 0; k < (AT_D / 2 * AT_KT) / 256; ++k) {
-            const int idx = tid + k * 256;
-            const int d2 = idx >> 6, j = idx & 63;
-            const int key = kt0 + j;
-            const bool ok = key < L;
-            const size_t off = (size_t)(2 * d2) * L + min(key, L - 1);
-            const float k0 = K[off], k1 = K[off + L];
-            mg_half2 hv;
-            hv[0] = (_Float16)(ok ? k0 : 0.f);
-            hv[1] = (_Float16)(ok ? k1 : 0.f);
-            *reinterpret_cast<mg_half2 *>(Kt + j * AH_KRS + 2 * d2) = hv;
+        for (int i = 0; i < 32; ++i) kreg[i] = kp[(size_t)i * L];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int d = (tid >> 4) + 16 * k, k4 = tid & 15;
+            const int f0 = kt0 + 4 * k4;
+            if (VEC) {
+                vreg[k] = *reinterpret_cast<const f32x4 *>(V + (size_t)d * L + min(f0, L - 4));
+                if (f0 >= L) vreg[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = V[(size_t)d * L + min(f0 + e, L - 1)];
+                    vreg[k][e] = f0 + e < L ? v : 0.f;
+                }
+            }
         }
-        // V: thread <-> (channel, key pair)
+        if (tid < AT_KT) kmasked = key >= L || (key_pad && key_pad[(size_t)b * L + kc]);
+        if (key >= L) {
 #pragma unroll
-        for (int k = 0; k < (AT_D * AT_KT / 2) / 256; ++k) {
-            const int idx = tid + k * 256;
-            const int d = idx >> 5, j2 = idx & 31;
-            const int key = kt0 + 2 * j2;
-            const size_t row = (size_t)d * L;
-            const float v0 = V[row + min(key, L - 1)], v1 = V[row + min(key + 1, L - 1)];
-            mg_half2 hv;
-            hv[0] = (_Float16)(key < L ? v0 : 0.f);
-            hv[1] = (_Float16)(key + 1 < L ? v1 : 0.f);
-            *reinterpret_cast<mg_half2 *>(Vt + d * AH_VRS + 2 * j2) = hv;
+            for (int i = 0; i < 32; ++i) kreg[i] = 0.f;
+        }
+    };
+    auto store_tile = [&]() {
+        _Float16 *kd = Kt + skey * AH_KRS + 32 * sdq;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            mg_half8 hv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hv[j] = (_Float16)kreg[8 * c + j];
+            *reinterpret_cast<mg_half8 *>(kd + 8 * c) = hv;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int d = (tid >> 4) + 16 * k, k4 = tid & 15;
+            // keys 4 k4 .. 4 k4 + 3: group of 16 = k4 >> 2, inside it quad (k4 & 3): h = quad & 1, hi = quad >> 1
+            const int pos = 16 * (k4 >> 2) + 8 * (k4 & 1) + 4 * ((k4 >> 1) & 1);
+            mg_half4 hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hv[e] = (_Float16)vreg[k][e];
+            *reinterpret_cast<mg_half4 *>(Vt + d * AH_VRS + pos) = hv;
         }
         if (tid < AT_KT) {
-            const int key = kt0 + tid;
-            const bool masked = key >= L || (key_pad && key_pad[(size_t)b * L + min(key, L - 1)]);
-            kmask[tid] = masked ? 1.f : 0.f;
+            const unsigned long long bal = __ballot(kmasked);
+            if (tid == 0) {
+                kmask[0] = (unsigned)bal;
+                kmask[1] = (unsigned)(bal >> 32);
+            }
         }
+    };
+
+    load_tile(0);
+    for (int kt0 = 0; kt0 < L; kt0 += AT_KT) {
+        __syncthreads();  // previous tile fully consumed
+        store_tile();
         __syncthreads();
+        if (kt0 + AT_KT < L) load_tile(kt0 + AT_KT);
 #pragma unroll
         for (int kb = 0; kb < AT_KT / 32; ++kb) {
             f32x16 S;
@@ -220,19 +312,15 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_f16_kernel(const float *
             for (int j = 0; j < 16; ++j) S[j] = 0.f;
             const _Float16 *Kp = Kt + (kb * 32 + r) * AH_KRS + 8 * hh;
 #pragma unroll
-            for (int s = 0; s < AT_D / 16; ++s) {
-                const mg_half4 lo = *reinterpret_cast<const mg_half4 *>(Kp + 16 * s);
-                const mg_half4 hi = *reinterpret_cast<const mg_half4 *>(Kp + 16 * s + 4);
-                const mg_half8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                S = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], S, 0, 0, 0);
-            }
+            for (int s = 0; s < AT_D / 16; ++s)
+                S = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const mg_half8 *>(Kp + 16 * s), qf[s], S, 0, 0, 0);
             // S[p] = score(key = kb*32 + 8(p>>2) + 4h + (p&3), query = r)
-            float mk[16];
+            const unsigned mw = kmask[kb] >> (4 * hh);
             float mx = AT_NEG;
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
-                mk[p] = kmask[kb * 32 + 8 * (p >> 2) + 4 * hh + (p & 3)];
-                const float v = mk[p] != 0.f ? AT_NEG : S[p];
+                const bool masked = (mw >> (8 * (p >> 2) + (p & 3))) & 1u;
+                const float v = masked ? AT_NEG : S[p];
                 S[p] = v;
                 mx = fmaxf(mx, v);
             }
@@ -242,17 +330,20 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_f16_kernel(const float *
             float ps = 0.f;
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
-                const float e = mk[p] != 0.f ? 0.f : __expf(S[p] - m_new);
+                const bool masked = (mw >> (8 * (p >> 2) + (p & 3))) & 1u;
+                const float e = masked ? 0.f : __expf(S[p] - m_new);
                 S[p] = e;
                 ps += e;
             }
             ps += __shfl_xor(ps, 32, 64);
             l_run = l_run * corr + ps;
+            if (__any(m_new != m_run)) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) O[i][j] *= corr;
+            }
             m_run = m_new;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 16; ++j) O[i][j] *= corr;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 mg_half8 pb;
@@ -260,11 +351,8 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_f16_kernel(const float *
                 for (int j = 0; j < 8; ++j) pb[j] = (_Float16)S[8 * t + j];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const _Float16 *Vp = Vt + (i * 32 + r) * AH_VRS + kb * 32 + 16 * t + 4 * hh;
-                    const mg_half4 lo = *reinterpret_cast<const mg_half4 *>(Vp);
-                    const mg_half4 hi = *reinterpret_cast<const mg_half4 *>(Vp + 8);
-                    const mg_half8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    O[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pb, O[i], 0, 0, 0);
+                    const _Float16 *Vp = Vt + (i * 32 + r) * AH_VRS + kb * 32 + 16 * t + 8 * hh;
+                    O[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const mg_half8 *>(Vp), pb, O[i], 0, 0, 0);
                 }
             }
         }
@@ -289,7 +377,9 @@ extern "C" int mg_attention_fwd_f16(const float *qkv, const uint8_t *key_pad, fl
     if (!qkv || !out) return MG_ERR_ARG;
     if (B <= 0 || L <= 0 || n_head <= 0 || d_head != AT_D) return MG_ERR_SHAPE;
     dim3 grid(mg_cdiv(L, 128), n_head, B);
-    hipLaunchKernelGGL(attention_fwd_f16_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, key_pad, out, L, n_head, scale);
+    const bool vec = (L % 4 == 0) && (((uintptr_t)qkv & 15) == 0);
+    if (vec) hipLaunchKernelGGL(attention_fwd_f16_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, qkv, key_pad, out, L, n_head, scale);
+    else hipLaunchKernelGGL(attention_fwd_f16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, qkv, key_pad, out, L, n_head, scale);
     MG_LAUNCH_CHECK();
     return MG_OK;
 }
@@ -300,7 +390,9 @@ extern "C" int mg_attention_fwd(const float *qkv, const uint8_t *key_pad, float 
     if (!qkv || !out) return MG_ERR_ARG;
     if (B <= 0 || L <= 0 || n_head <= 0 || d_head != AT_D) return MG_ERR_SHAPE;
     dim3 grid(mg_cdiv(L, 128), n_head, B);
-    hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, qkv, key_pad, out, L, n_head, scale);
+    const bool vec = (L % 4 == 0) && (((uintptr_t)qkv & 15) == 0);
+    if (vec) hipLaunchKernelGGL(attention_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, qkv, key_pad, out, L, n_head, scale);
+    else hipLaunchKernelGGL(attention_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, qkv, key_pad, out, L, n_head, scale);
     MG_LAUNCH_CHECK();
     return MG_OK;
 }
