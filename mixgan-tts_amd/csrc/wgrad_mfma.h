@@ -19,6 +19,8 @@
 // between the two barriers of a chunk where nothing overlaps them: 253-259 us per launch against 221 us.
 #pragma once
 #include "common.h"
+#include "wgrad_stream.h"
+#include <cstdlib>
 
 #define WG_FT 64
 #define WG_RSA 65   // odd strides: the 32 lanes of a fragment read (32 rows, one column) hit 32 banks
@@ -246,7 +248,10 @@ static inline int wgrad_nsplit(int Co, int Ci, int K, int G = 1)
 }
 static inline size_t wgrad_scratch_floats(int Co, int Ci, int K, int G = 1)
 {
-    return (size_t)wgrad_nsplit(Co, Ci, K, G) * G * Co * Ci * K;
+    // either kernel may run (the streaming one needs aligned, stride-1 operands): size for both
+    const size_t split = (size_t)wgrad_nsplit(Co, Ci, K, G) * G * Co * Ci * K;
+    const size_t stream = wgrad_stream_scratch_floats(Co, Ci, K, G);
+    return split > stream ? split : stream;
 }
 
 struct WgradShape {
@@ -286,6 +291,28 @@ static int wgrad_launch(const WgradShape &s, const float *dy, const float *x, co
     a.nsplit = nsplit;
     const size_t n = (size_t)s.Co * s.Ci * s.K * s.G;
     dim3 grid(nsplit, mg_cdiv(s.Co, 128) * a.ci_tiles, s.K * s.G);
+    {   // big stride-1 "same" gradients: the streaming kernel (wgrad_stream.h); MG_WGRAD_STREAM=0 keeps the split kernel
+        const char *env = std::getenv("MG_WGRAD_STREAM");
+        const bool stream_on = !(env && env[0] == '0');
+        const long dybs = a.dy_bs, xbs = a.x_bs;
+        const long long units = (long long)wgrad_stream_tiles(s.Co, s.Ci, s.K, s.G) * s.B *
+                                mg_cdiv(s.Ldy, s.K == 3 ? WsCfg<3>::FT : WsCfg<1>::FT);
+        const bool ok = stream_on && s.stride == 1 && !xvec && (s.K == 1 || s.K == 3) && s.pad == (s.K - 1) / 2 &&
+                        s.Ldy == s.Lx && s.Ldy % 4 == 0 && s.Ldy >= 4 && wgrad_stream_shape_ok(s.Co, s.Ci, s.K) &&
+                        dybs % 4 == 0 && xbs % 4 == 0 && s.dy_gs % 4 == 0 && s.x_gs % 4 == 0 &&
+                        ((((uintptr_t)dy | (uintptr_t)x) & 15) == 0) &&
+                        units * 2 < (1ll << 31) &&
+                        // at least one unit per CU; smaller gradients stay on the split kernel
+                        units >= WS_NW;
+        if (ok) {
+            const long dwgs = s.dw_gs ? s.dw_gs : (long)s.Co * s.Ci * s.K;
+            if (s.K == 3)
+                return wgrad_stream_launch_k<3>(dy, x, dw, scratch, s.G, s.B, s.Co, s.Ci, s.Ldy, dybs, xbs, s.dy_gs, s.x_gs,
+                                                dwgs, alpha, accumulate, st);
+            return wgrad_stream_launch_k<1>(dy, x, dw, scratch, s.G, s.B, s.Co, s.Ci, s.Ldy, dybs, xbs, s.dy_gs, s.x_gs, dwgs,
+                                            alpha, accumulate, st);
+        }
+    }
     const bool vec = s.stride == 1 && !xvec && (s.Ldy % 4 == 0) && (s.Lx % 4 == 0) && (a.dy_bs % 4 == 0) &&
                      (a.x_bs % 4 == 0) && (a.dy_gs % 4 == 0) && (a.x_gs % 4 == 0) && ((((uintptr_t)dy | (uintptr_t)x) & 15) == 0) && s.Ldy >= 4 && s.Lx >= 4;
     if (vec) hipLaunchKernelGGL(wgrad_mfma_kernel<true>, grid, dim3(256), 0, st, a);

@@ -127,6 +127,57 @@ def test_denoiser_backward_vs_oracle_autograd_ragged(mg, manifest, tmp_path):
         assert_close(p.grad.cpu(), W[k].grad, 1e-4, k)
 
 
+@pytest.mark.parametrize("Ci,Co,K,B,L", [(256, 512, 3, 4, 1000), (256, 256, 1, 8, 1004), (128, 128, 3, 129, 68),
+                                         (256, 128, 1, 130, 36), (256, 640, 1, 3, 1000)])
+def test_wgrad_streaming_kernel(mg, monkeypatch, Ci, Co, K, B, L):
+    """Shapes the streaming kernel (wgrad_stream.h) takes: against autograd, and against the split kernel
+    (MG_WGRAD_STREAM=0) that the small shapes above run on."""
+    g = torch.Generator().manual_seed(Ci + Co * 7 + K + L)
+    x = torch.randn(B, Ci, L, generator=g)
+    w = (torch.randn(Co, Ci, K, generator=g) / (Ci * K) ** 0.5).requires_grad_()
+    y = F.conv1d(x, w, None, padding=(K - 1) // 2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    gyc, xc = gy.cuda(), x.cuda()
+    dw = mg.ops.conv1d_wgrad(gyc, xc, K, 1, (K - 1) // 2)
+    assert_close(dw.cpu(), w.grad, 2e-5, "streaming wgrad vs autograd")
+    assert torch.equal(dw, mg.ops.conv1d_wgrad(gyc, xc, K, 1, (K - 1) // 2)), "summation order must not change run to run"
+    monkeypatch.setenv("MG_WGRAD_STREAM", "0")
+    dw0 = mg.ops.conv1d_wgrad(gyc, xc, K, 1, (K - 1) // 2)
+    assert not torch.equal(dw, dw0), "both calls ran the same kernel"
+    assert_close(dw.cpu(), dw0.cpu(), 2e-5, "streaming vs split kernel")
+
+
+def test_grouped_wgrad_streaming(mg, monkeypatch):
+    """The residual stack's grouped gradients on the streaming kernel: layer slots inside wider tensors, a shared dY
+    (group stride 0), alpha and accumulation; a workgroup's run of units crosses tile and group boundaries."""
+    import ctypes
+    G, B, Co, Ci, K, L = 3, 6, 256, 128, 3, 520
+    gen = torch.Generator().manual_seed(13)
+    dy_all = torch.randn(B, G * Co, L, generator=gen).cuda()
+    x_all = torch.randn(G, B, Ci, L, generator=gen).cuda()
+    lib = mg._lib.lib()
+    cp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    scratch = torch.empty(lib.mg_conv1d_wgrad_grouped_scratch_floats(Co, Ci, K, G), device="cuda")
+
+    def run(dy_gs, alpha, acc, out):
+        mg._lib.check(lib.mg_conv1d_wgrad_grouped(cp(dy_all), G * Co * L, dy_gs, cp(x_all), Ci * L, B * Ci * L, cp(out), 0,
+                                                  cp(scratch), G, B, Co, Ci, L, L, K, 1, 1, alpha, acc, None))
+        return out
+    dw = run(Co * L, 1.0, 0, torch.empty(G, Co, Ci, K, device="cuda"))
+    dw2 = run(0, 0.5, 1, torch.ones(G, Co, Ci, K, device="cuda"))
+    monkeypatch.setenv("MG_WGRAD_STREAM", "0")
+    ref = run(Co * L, 1.0, 0, torch.empty(G, Co, Ci, K, device="cuda"))
+    ref2 = run(0, 0.5, 1, torch.ones(G, Co, Ci, K, device="cuda"))
+    assert not torch.equal(dw, ref)
+    assert_close(dw.cpu(), ref.cpu(), 2e-5, "grouped streaming wgrad")
+    assert_close(dw2.cpu(), ref2.cpu(), 2e-5, "grouped streaming wgrad, shared dy + accumulate")
+    xr = x_all[1].cpu()
+    w = torch.zeros(Co, Ci, K, requires_grad=True)
+    F.conv1d(xr, w, None, padding=1).backward(dy_all[:, Co:2 * Co].cpu())
+    assert_close(dw[1].cpu(), w.grad, 2e-5, "grouped streaming wgrad vs autograd")
+
+
 def test_grouped_wgrad_matches_per_group_calls(mg):
     """mg_conv1d_wgrad_grouped: G gradients of one shape in one launch (shared or per-group operands, strided
     slots inside wider tensors) == G separate mg_conv1d_wgrad calls."""
