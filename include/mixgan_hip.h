@@ -336,6 +336,20 @@ int mg_bn_act_bwd_apply(const float *dout, const uint8_t *keep, float drop_scale
                         const float *mean, const float *invstd, const float *gamma, const float *dgamma,
                         const float *dbeta, float inv_count, int act, float *dx, int B, int C, int L, void *stream);
 
+/* ------------------------------------------------------------------ optimizer step on flat buffers
+ * The update of train.py:75-85 per optimizer -- nn.utils.clip_grad_norm_(params, clip) then Adam.step()
+ * (utils/model.py:32-40 builds torch.optim.Adam(lr, betas)) -- with gradients, parameters and both moments each in
+ * ONE flat fp32 buffer of n elements (16-byte aligned):
+ * mg_grad_norm: out[0] = ||g||_2 (fixed summation order), out[1] = min(1, max_norm / (out[0] + 1e-6)), the factor
+ *   clip_grad_norm_ multiplies into every gradient; scratch holds mg_grad_norm_scratch_floats() floats.
+ * mg_adam_flat: one Adam step (torch.optim.Adam's rule: L2 weight decay, m lerp, bias corrections from `step` >= 1,
+ *   denom = sqrt(v)/sqrt(1-beta2^step) + eps) on g * grad_scale[0] (device scalar, e.g. out + 1 above; NULL = 1).
+ *   g is not modified. */
+size_t mg_grad_norm_scratch_floats(void);
+int mg_grad_norm(const float *g, size_t n, float max_norm, float *scratch, float *out, void *stream);
+int mg_adam_flat(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, long step, const float *grad_scale, void *stream);
+
 /* ------------------------------------------------------------------ losses on the path (model/loss.py)
  * mg_loss_sum: out[0] = sum (a-c)^2 (mode 0: F.mse_loss against a constant label, loss.py:14-19)
  *              or sum |a-b| (mode 1: F.l1_loss numerator, loss.py:221-227); the caller divides by n.

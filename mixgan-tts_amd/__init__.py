@@ -16,7 +16,9 @@ from .discriminator import JCUDiscriminator  # noqa: F401
 from . import ops, autograd, losses, distributed  # noqa: F401
 from .train_step import HotPathTrainer, AuxTrainer  # noqa: F401
 from . import lingops, vocoder, data  # noqa: F401
-from .optimizer import ScheduledOptim  # noqa: F401
+from . import optimizer  # noqa: F401
+from .optimizer import ScheduledOptim, FlatAdam  # noqa: F401
+from .distributed import GradBucket  # noqa: F401
 from .mixgantts import MixGANTTS, get_mask_from_lengths  # noqa: F401
 from .transformer import Decoder, FFTBlock, PostNet, MultiHeadAttention, PositionwiseFeedForward  # noqa: F401
 from .model_io import get_model, save_checkpoint, get_param_num  # noqa: F401

@@ -24,6 +24,7 @@ EXPORTS = (
     "mg_length_regulate_fwd", "mg_length_regulate_bwd", "mg_word_pool_fwd", "mg_word_pool_bwd", "mg_mapping_mask",
     "mg_rel_coef", "mg_resblock_fwd", "mg_gate_bwd", "mg_mish_fwd", "mg_mish_bwd", "mg_step_embed",
     "mg_denoiser_psample", "mg_denoiser_persist_status",
+    "mg_grad_norm_scratch_floats", "mg_grad_norm", "mg_adam_flat",
 )
 
 
@@ -114,6 +115,9 @@ def _declare(L):
         "mg_linear_small_fwd": (i, [vp, vp, vp, i, i, i, vp]),
         "mg_linear_small_bwd": (i, [vp, vp, vp, vp, vp, i, i, i, vp]),
         "mg_loss_sum": (i, [vp, vp, f, i, sz, vp, vp]),
+        "mg_grad_norm_scratch_floats": (sz, []),
+        "mg_grad_norm": (i, [vp, sz, f, vp, vp, vp]),
+        "mg_adam_flat": (i, [vp, vp, vp, vp, sz, f, f, f, f, f, lg, vp, vp]),
         "mg_loss_grad": (i, [vp, vp, f, i, vp, f, sz, vp, vp]),
         "mg_mel_l1_fwd": (i, [vp, vp, vp, i, i, vp, vp]),
         "mg_mel_l1_bwd": (i, [vp, vp, vp, i, i, vp, vp, vp, vp]),

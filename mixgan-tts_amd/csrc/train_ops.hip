@@ -359,3 +359,138 @@ extern "C" int mg_bn_act_bwd_apply(const float *dout, const uint8_t *keep, float
     MG_LAUNCH_CHECK();
     return MG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Optimizer step on flat buffers (train.py:75-85: clip_grad_norm_ + Adam.step per optimizer)
+// ---------------------------------------------------------------------------------------------
+// The gradients of one optimizer already live in one flat buffer (distributed.py GradBucket); with the parameters and
+// both moments flat as well, clip + Adam is two launches that move 4 + 28 bytes per parameter: a fixed-order
+// sum of squares, then one pass that scales the gradient by the clip factor on the fly and updates p, m, v.
+#define GN_BLOCKS 1024
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float *__restrict__ g, size_t n, float *__restrict__ partial)
+{
+    __shared__ float red[4];
+    const size_t n4 = n >> 2, stride = (size_t)gridDim.x * 256;
+    float s = 0.f;
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const f32x4 v = g4[i];
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float v = g[(n4 << 2) + threadIdx.x];
+        s += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// out[0] = ||g||_2, out[1] = min(1, max_norm / (||g|| + 1e-6))  (torch.nn.utils.clip_grad_norm_)
+__global__ __launch_bounds__(256) void grad_norm_finish_kernel(const float *__restrict__ partial, int nblocks, float max_norm,
+                                                               float *__restrict__ out)
+{
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += (double)partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
+        out[0] = norm;
+        const float c = max_norm / (norm + 1e-6f);
+        out[1] = max_norm > 0.f ? (c < 1.f ? c : 1.f) : 1.f;
+    }
+}
+
+struct AdamArgs {
+    float *p, *m, *v;
+    const float *g;
+    const float *scale;   // device scalar multiplied into g (the clip factor), or null
+    size_t n;
+    float lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, weight_decay;
+};
+
+__device__ __forceinline__ void adam_one(float &p, float &m, float &v, float g, const AdamArgs &a)
+{
+    if (a.weight_decay != 0.f) g += a.weight_decay * p;          // L2 form of torch.optim.Adam
+    m += (1.f - a.beta1) * (g - m);                              // lerp, as torch's _single_tensor_adam
+    v = a.beta2 * v + (1.f - a.beta2) * g * g;
+    const float denom = sqrtf(v) * a.inv_sqrt_bc2 + a.eps;
+    p -= a.lr_over_bc1 * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adam_flat_kernel(AdamArgs a)
+{
+    const float sc = a.scale ? a.scale[0] : 1.f;
+    const size_t n4 = a.n >> 2, stride = (size_t)gridDim.x * 256;
+    f32x4 *p4 = reinterpret_cast<f32x4 *>(a.p), *m4 = reinterpret_cast<f32x4 *>(a.m), *v4 = reinterpret_cast<f32x4 *>(a.v);
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(a.g);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        f32x4 p = p4[i], m = m4[i], v = v4[i];
+        const f32x4 g = g4[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float pj = p[j], mj = m[j], vj = v[j];
+            adam_one(pj, mj, vj, g[j] * sc, a);
+            p[j] = pj;
+            m[j] = mj;
+            v[j] = vj;
+        }
+        p4[i] = p;
+        m4[i] = m;
+        v4[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
+        const size_t i = (n4 << 2) + threadIdx.x;
+        adam_one(a.p[i], a.m[i], a.v[i], a.g[i] * sc, a);
+    }
+}
+
+extern "C" size_t mg_grad_norm_scratch_floats(void) { return GN_BLOCKS; }
+
+extern "C" int mg_grad_norm(const float *g, size_t n, float max_norm, float *scratch, float *out, void *stream)
+{
+    if (!g || !scratch || !out) return MG_ERR_ARG;
+    if (n == 0) return MG_ERR_SHAPE;
+    if (((uintptr_t)g & 15) != 0) return MG_ERR_ARG;
+    const size_t want = (n / 4 + 255) / 256;
+    const int blocks = (int)(want < 1 ? 1 : (want > GN_BLOCKS ? GN_BLOCKS : want));
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, scratch);
+    MG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(grad_norm_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, blocks, max_norm, out);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
+}
+
+extern "C" int mg_adam_flat(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, long step, const float *grad_scale, void *stream)
+{
+    if (!p || !g || !m || !v) return MG_ERR_ARG;
+    if (n == 0 || step < 1) return MG_ERR_SHAPE;
+    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return MG_ERR_ARG;
+    AdamArgs a;
+    a.p = p;
+    a.m = m;
+    a.v = v;
+    a.g = g;
+    a.scale = grad_scale;
+    a.n = n;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    a.lr_over_bc1 = (float)((double)lr / bc1);
+    a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    a.beta1 = beta1;
+    a.beta2 = beta2;
+    a.eps = eps;
+    a.weight_decay = weight_decay;
+    const size_t want = (n / 4 + 255) / 256;
+    const int blocks = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+    hipLaunchKernelGGL(adam_flat_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
+}

@@ -434,3 +434,21 @@ def step_embed(t, freq):
     emb = torch.empty(B, D, device=t.device, dtype=torch.float32)
     check(_lib.lib().mg_step_embed(iptr(t, torch.int64), fptr(freq), fptr(emb), B, D, stream_ptr()))
     return emb
+
+
+def grad_norm(flat, max_norm, out=None, scratch=None):
+    """(||flat||_2, clip factor min(1, max_norm / (norm + 1e-6))) as a 2-element device tensor (no host sync)."""
+    L = _lib.lib()
+    if out is None:
+        out = torch.empty(2, device=flat.device, dtype=torch.float32)
+    if scratch is None:
+        scratch = torch.empty(L.mg_grad_norm_scratch_floats(), device=flat.device, dtype=torch.float32)
+    check(L.mg_grad_norm(fptr(flat), flat.numel(), float(max_norm), fptr(scratch), fptr(out), stream_ptr()))
+    return out
+
+
+def adam_flat(p, g, m, v, lr, betas, eps, weight_decay, step, grad_scale=None):
+    """One torch.optim.Adam step on flat buffers, in place on p, m, v; g * grad_scale[0] is the gradient used."""
+    L = _lib.lib()
+    check(L.mg_adam_flat(fptr(p), fptr(g), fptr(m), fptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]),
+                         float(eps), float(weight_decay), int(step), fptr(grad_scale, True), stream_ptr()))

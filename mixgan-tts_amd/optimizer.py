@@ -60,3 +60,81 @@ class ScheduledOptim:
 
     def load_state_dict(self, adam_state):
         self._optimizer.load_state_dict(adam_state)
+
+
+class FlatAdam(torch.optim.Adam):
+    """torch.optim.Adam (utils/model.py:32-40) for parameters whose gradients sit in a `GradBucket`: the parameters
+    and both moments are re-homed into flat buffers with the bucket's layout, so that `clip_grad_norm_` + `step()` of
+    train.py:81-83 become two HIP launches (ops.grad_norm, ops.adam_flat) at 32 bytes of HBM traffic per parameter,
+    instead of a norm, a scale and ~10 multi-tensor launches.  Same update rule, same `state_dict()` layout (per
+    parameter `step`, `exp_avg`, `exp_avg_sq` -- here views of the flat moments), same `param_groups` (lr schedulers
+    work unchanged).  Build it after the module is on its device; `.to()` afterwards would undo the aliasing."""
+
+    def __init__(self, bucket, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(bucket.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.bucket = bucket
+        flat = bucket.flat
+        if not flat.is_cuda:
+            raise ValueError("FlatAdam runs on the HIP path; keep torch.optim.Adam for CPU parameters")
+        self.flat_p = torch.empty_like(flat)
+        self.flat_m = torch.zeros_like(flat)
+        self.flat_v = torch.zeros_like(flat)
+        self._norm = torch.zeros(2, device=flat.device, dtype=torch.float32)
+        self._scratch = None
+        self._steps = torch.tensor(0.0)                   # shared by every parameter's state (they step together)
+        for p in bucket.params:
+            off, n = bucket.offsets[id(p)], p.numel()
+            home = self.flat_p[off:off + n].view_as(p)
+            home.copy_(p.data)
+            p.data = home
+            self.state[p] = {"step": self._steps, "exp_avg": self.flat_m[off:off + n].view_as(p),
+                             "exp_avg_sq": self.flat_v[off:off + n].view_as(p)}
+
+    @torch.no_grad()
+    def step(self, closure=None, max_grad_norm=None):
+        """Adam step from bucket.flat (call bucket.gather()/all_reduce_mean() first).  max_grad_norm: clip the global
+        gradient norm first, like clip_grad_norm_(params, max_grad_norm) -- the factor is applied inside the update;
+        bucket.flat itself is left unscaled.  Returns the device tensor (norm, factor) when clipping."""
+        from . import ops
+        if closure is not None:
+            raise NotImplementedError("FlatAdam.step takes no closure")
+        g = self.param_groups[0]
+        if len(self.param_groups) != 1 or g.get("amsgrad") or g.get("maximize"):
+            raise NotImplementedError("FlatAdam: one parameter group, no amsgrad / maximize")
+        scale = None
+        if max_grad_norm is not None:
+            if self._scratch is None:
+                self._scratch = torch.empty(ops._lib.lib().mg_grad_norm_scratch_floats(), device=self.flat_p.device)
+            ops.grad_norm(self.bucket.flat, max_grad_norm, out=self._norm, scratch=self._scratch)
+            scale = self._norm[1:]
+        self._steps += 1
+        ops.adam_flat(self.flat_p, self.bucket.flat, self.flat_m, self.flat_v, g["lr"], g["betas"], g["eps"],
+                      g["weight_decay"], int(self._steps.item()), scale)
+        torch.autograd.graph.increment_version(self.bucket.params)    # derived caches (packed weights) key on it
+        return self._norm if max_grad_norm is not None else None
+
+    def state_dict(self):
+        """torch.optim.Adam's layout.  Every parameter gets its OWN `step` tensor: a stock Adam that loads this
+        increments the step of each parameter separately, and must not find them aliased."""
+        sd = super().state_dict()
+        sd["state"] = {k: dict(st, step=st["step"].clone()) for k, st in sd["state"].items()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        """Accepts a torch.optim.Adam state dict (the reference's checkpoints, train.py:252-267): the moments are
+        copied into the flat buffers and the state re-pointed at them."""
+        super().load_state_dict(state_dict)
+        steps = 0.0
+        for p in self.bucket.params:
+            st = self.state.get(p)
+            off, n = self.bucket.offsets[id(p)], p.numel()
+            m, v = self.flat_m[off:off + n].view_as(p), self.flat_v[off:off + n].view_as(p)
+            if st:
+                m.copy_(st["exp_avg"])
+                v.copy_(st["exp_avg_sq"])
+                steps = max(steps, float(st["step"]))
+            else:
+                m.zero_()
+                v.zero_()
+            self.state[p] = {"step": self._steps, "exp_avg": m, "exp_avg_sq": v}
+        self._steps.fill_(steps)

@@ -16,6 +16,7 @@ import torch
 
 from . import losses
 from .distributed import GradBucket
+from .optimizer import FlatAdam
 
 
 class HotPathTrainer:
@@ -29,19 +30,21 @@ class HotPathTrainer:
             raise NotImplementedError("HotPathTrainer steps the optimizers every call (train.py:77-85 with "
                                       "grad_acc_step = 1, the value every shipped config sets)")
         g_params = list(diffusion.parameters()) + list(extra_g_params)
-        # utils/model.py:32-40.  On the GPU the optimizer runs as fused multi-tensor kernels (same update rule; ~50
-        # foreach launches per step otherwise)
-        fused = {"fused": True} if g_params and g_params[0].is_cuda else {}
-        self.optG = torch.optim.Adam(g_params, lr=oc["init_lr_G"], betas=oc["betas"], **fused)
-        self.optD = torch.optim.Adam(discriminator.parameters(), lr=oc["init_lr_D"], betas=oc["betas"], **fused)
+        # the denoiser's backward writes its weight gradients straight into the G bucket (no gather copy)
+        self.bucketG = GradBucket(g_params, order=diffusion.denoise_fn.grad_order())
+        self.bucketD = GradBucket(list(discriminator.parameters()))
+        # utils/model.py:32-40: Adam(lr, betas) per network.  On the GPU: FlatAdam (optimizer.py) -- parameters and
+        # moments flat like the gradients, clip + step in two launches; on CPU (tests) torch's own
+        if self.bucketG.flat.is_cuda:
+            diffusion.denoise_fn.bind_grad_buffer(self.bucketG.flat, self.bucketG.offsets)
+            self.optG = FlatAdam(self.bucketG, lr=oc["init_lr_G"], betas=oc["betas"])
+            self.optD = FlatAdam(self.bucketD, lr=oc["init_lr_D"], betas=oc["betas"])
+        else:
+            self.optG = torch.optim.Adam(g_params, lr=oc["init_lr_G"], betas=oc["betas"])
+            self.optD = torch.optim.Adam(discriminator.parameters(), lr=oc["init_lr_D"], betas=oc["betas"])
         self.sdlG = torch.optim.lr_scheduler.ExponentialLR(self.optG, gamma=oc["gamma"])    # stepped per EPOCH
         self.sdlD = torch.optim.lr_scheduler.ExponentialLR(self.optD, gamma=oc["gamma"])
         self.d_loss_fn, self.g_loss_fn = losses.get_adversarial_losses_fn(train_config["loss"]["adv_loss_mode"])
-        # the denoiser's backward writes its weight gradients straight into the G bucket (no gather copy)
-        self.bucketG = GradBucket(g_params, order=diffusion.denoise_fn.grad_order())
-        if self.bucketG.flat.is_cuda:
-            diffusion.denoise_fn.bind_grad_buffer(self.bucketG.flat, self.bucketG.offsets)
-        self.bucketD = GradBucket(list(discriminator.parameters()))
 
     grad_hook = None      # optional callable(name, bucket) after the gradient exchange, before clipping (tests, logging)
 
@@ -49,10 +52,14 @@ class HotPathTrainer:
         bucket.all_reduce_mean()                      # no-op on one process
         if self.grad_hook is not None:
             self.grad_hook("G" if bucket is self.bucketG else "D", bucket)
-        # clip_grad_norm_(params, clip) of train.py:81 on the flat bucket every .grad now aliases: one norm, one scale
-        total = torch.linalg.vector_norm(bucket.flat)
-        bucket.flat.mul_(torch.clamp(self.grad_clip / (total + 1e-6), max=1.0))
-        opt.step()
+        if isinstance(opt, FlatAdam):
+            # clip_grad_norm_(params, clip) of train.py:81 folded into the update: one norm pass, one Adam pass
+            opt.step(max_grad_norm=self.grad_clip)
+        else:
+            # ... on the flat bucket every .grad now aliases: one norm, one scale
+            total = torch.linalg.vector_norm(bucket.flat)
+            bucket.flat.mul_(torch.clamp(self.grad_clip / (total + 1e-6), max=1.0))
+            opt.step()
         opt.zero_grad()                               # after step, as train.py:84-85
 
     def _d_fake_and_real(self, x_ts, x_fake, x_real, spk, t):
