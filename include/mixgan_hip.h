@@ -357,6 +357,29 @@ int mg_adam_flat(float *p, const float *g, float *m, float *v, size_t n, float l
 int mg_loss_sum(const float *a, const float *b, float c, int mode, size_t n, float *out, void *stream);
 int mg_loss_grad(const float *a, const float *b, float c, int mode, const float *g, float coef, size_t n,
                  float *da, void *stream);
+/* A weighted sum of mean-reduced terms in one launch: total = sum_k weight_k * mean_k, mean_k = mean (a-c)^2
+ * (mode 0) or mean |a-b| (mode 1) over n elements -- the LSGAN pair of model/loss.py:12-30 and the feature-matching
+ * sum of model/loss.py:221-227 are such sums.  out[0] = total, out[1+q] = the weighted subtotal of the terms with
+ * group == q (q < MG_LOSS_GROUPS; e.g. adversarial and feature-matching parts for logging),
+ * out[1+MG_LOSS_GROUPS+k] = mean_k; fixed summation order.  scratch:
+ * mg_multi_loss_scratch_floats() floats, ZERO before the first call (the kernel keeps a ticket in it and re-arms it),
+ * private to one stream.  mg_multi_loss_bwd: da_k = g[0] * weight_k / n_k * {2(a-c) | sign(a-b)} for every term
+ * whose da is not NULL. */
+#define MG_LOSS_MAX_TERMS 16
+#define MG_LOSS_GROUPS 4
+typedef struct MgLossTerm {
+    const float *a;
+    const float *b;   /* mode 1 only */
+    float *da;        /* backward only; NULL = no gradient wanted */
+    size_t n;
+    float c;          /* mode 0 only */
+    float weight;
+    int32_t mode;
+    int32_t group;
+} MgLossTerm;
+size_t mg_multi_loss_scratch_floats(void);
+int mg_multi_loss_fwd(const MgLossTerm *terms, int nterms, float *scratch, float *out, void *stream);
+int mg_multi_loss_bwd(const MgLossTerm *terms, int nterms, const float *g, void *stream);
 /* Masked mel L1 (loss.py:229-242,255-259) over rows = B*L frames of M bins, pad uint8 [rows] (1 = pad):
  * out2 = {sum |p-t| over counted rows, M * #counted rows}; the loss is out2[0]/out2[1]. */
 int mg_mel_l1_fwd(const float *pred, const float *targ, const uint8_t *pad, int rows, int M, float *out2,

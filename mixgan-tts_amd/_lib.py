@@ -25,11 +25,21 @@ EXPORTS = (
     "mg_rel_coef", "mg_resblock_fwd", "mg_gate_bwd", "mg_mish_fwd", "mg_mish_bwd", "mg_step_embed",
     "mg_denoiser_psample", "mg_denoiser_persist_status",
     "mg_grad_norm_scratch_floats", "mg_grad_norm", "mg_adam_flat",
+    "mg_multi_loss_scratch_floats", "mg_multi_loss_fwd", "mg_multi_loss_bwd",
 )
 
 
 class MixganHipError(RuntimeError):
     pass
+
+
+MG_LOSS_MAX_TERMS = 16
+MG_LOSS_GROUPS = 4
+
+
+class LossTerm(ctypes.Structure):
+    _fields_ = [("a", ctypes.c_void_p), ("b", ctypes.c_void_p), ("da", ctypes.c_void_p), ("n", ctypes.c_size_t),
+                ("c", ctypes.c_float), ("weight", ctypes.c_float), ("mode", ctypes.c_int32), ("group", ctypes.c_int32)]
 
 
 class DenoiserDims(ctypes.Structure):
@@ -115,6 +125,9 @@ def _declare(L):
         "mg_linear_small_fwd": (i, [vp, vp, vp, i, i, i, vp]),
         "mg_linear_small_bwd": (i, [vp, vp, vp, vp, vp, i, i, i, vp]),
         "mg_loss_sum": (i, [vp, vp, f, i, sz, vp, vp]),
+        "mg_multi_loss_scratch_floats": (sz, []),
+        "mg_multi_loss_fwd": (i, [vp, i, vp, vp, vp]),
+        "mg_multi_loss_bwd": (i, [vp, i, vp, vp]),
         "mg_grad_norm_scratch_floats": (sz, []),
         "mg_grad_norm": (i, [vp, sz, f, vp, vp, vp]),
         "mg_adam_flat": (i, [vp, vp, vp, vp, sz, f, f, f, f, f, lg, vp, vp]),

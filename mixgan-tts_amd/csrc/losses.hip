@@ -141,3 +141,142 @@ extern "C" int mg_mel_l1_bwd(const float *pred, const float *targ, const uint8_t
     MG_LAUNCH_CHECK();
     return MG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Weighted sum of up to MG_LOSS_MAX_TERMS mean-reduced terms in ONE launch (and ONE for its gradient).
+// The adversarial + feature-matching part of the generator loss is ten such terms (model/loss.py:12-30,221-227);
+// one launch pair per term plus the scalar arithmetic between them was ~110 launches of a few microseconds each
+// per training step.  Per-block partial sums land in scratch; the last block to finish adds them in index order
+// (fixed summation order), writes the total and the per-term means, and re-arms the ticket.
+// ---------------------------------------------------------------------------------------------
+struct MultiLossArgs {
+    MgLossTerm t[MG_LOSS_MAX_TERMS];
+    int first_block[MG_LOSS_MAX_TERMS + 1];
+    int nterms;
+    float *partial;      // [total blocks]
+    unsigned *ticket;    // zero before the first launch; re-armed by the kernel
+    float *out;          // [1 + MG_LOSS_GROUPS + nterms]: total, group subtotals, then each term's unweighted mean
+    const float *g;      // backward: upstream gradient (device scalar)
+};
+
+__device__ __forceinline__ int ml_term_of(const MultiLossArgs &a, int block)
+{
+    int k = 0;
+    while (k + 1 < a.nterms && block >= a.first_block[k + 1]) ++k;
+    return k;
+}
+
+__global__ __launch_bounds__(256) void multi_loss_fwd_kernel(MultiLossArgs a)
+{
+    __shared__ float red[4];
+    __shared__ unsigned last;
+    const int k = ml_term_of(a, blockIdx.x);
+    const MgLossTerm t = a.t[k];
+    const int nb = a.first_block[k + 1] - a.first_block[k], lb = blockIdx.x - a.first_block[k];
+    float s = 0.f;
+    for (size_t i = (size_t)lb * 256 + threadIdx.x; i < t.n; i += (size_t)nb * 256) {
+        const float d = t.mode == 0 ? t.a[i] - t.c : t.a[i] - t.b[i];
+        s += t.mode == 0 ? d * d : fabsf(d);
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(a.partial + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = atomicAdd(a.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (threadIdx.x < 64) {
+        // wave 0: lane j < nterms adds its term's partials in block order
+        float total = 0.f;
+        if ((int)threadIdx.x < a.nterms) {
+            const int j = threadIdx.x;
+            float sj = 0.f;
+            for (int b = a.first_block[j]; b < a.first_block[j + 1]; ++b)
+                sj += __hip_atomic_load(a.partial + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float mean = a.t[j].n ? sj / (float)a.t[j].n : 0.f;
+            a.out[1 + MG_LOSS_GROUPS + j] = mean;
+            total = a.t[j].weight * mean;
+        }
+        // terms in index order: every lane adds them one by one (nterms <= 16); lane 0 writes
+        float acc = 0.f, grp[MG_LOSS_GROUPS];
+#pragma unroll
+        for (int q = 0; q < MG_LOSS_GROUPS; ++q) grp[q] = 0.f;
+        for (int j = 0; j < a.nterms; ++j) {
+            const float w = __shfl(total, j, 64);
+            acc += w;
+#pragma unroll
+            for (int q = 0; q < MG_LOSS_GROUPS; ++q)
+                if (a.t[j].group == q) grp[q] += w;
+        }
+        if (threadIdx.x == 0) {
+            a.out[0] = acc;
+#pragma unroll
+            for (int q = 0; q < MG_LOSS_GROUPS; ++q) a.out[1 + q] = grp[q];
+            *a.ticket = 0u;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void multi_loss_bwd_kernel(MultiLossArgs a)
+{
+    const int k = ml_term_of(a, blockIdx.x);
+    const MgLossTerm t = a.t[k];
+    if (!t.da) return;
+    const int nb = a.first_block[k + 1] - a.first_block[k], lb = blockIdx.x - a.first_block[k];
+    const float kk = a.g[0] * t.weight / (float)t.n;
+    for (size_t i = (size_t)lb * 256 + threadIdx.x; i < t.n; i += (size_t)nb * 256) {
+        const float d = t.mode == 0 ? t.a[i] - t.c : t.a[i] - t.b[i];
+        t.da[i] = t.mode == 0 ? 2.f * kk * d : (d > 0.f ? kk : (d < 0.f ? -kk : 0.f));
+    }
+}
+
+static int multi_loss_fill(MultiLossArgs &a, const MgLossTerm *terms, int nterms, int max_blocks_per_term)
+{
+    if (!terms || nterms < 1 || nterms > MG_LOSS_MAX_TERMS) return MG_ERR_ARG;
+    int at = 0;
+    for (int k = 0; k < nterms; ++k) {
+        const MgLossTerm &t = terms[k];
+        if (!t.a || (t.mode == 1 && !t.b) || t.mode < 0 || t.mode > 1 || t.group < 0 || t.group >= MG_LOSS_GROUPS)
+            return MG_ERR_ARG;
+        if (t.n == 0) return MG_ERR_SHAPE;
+        a.t[k] = t;
+        a.first_block[k] = at;
+        const size_t want = (t.n + 2047) / 2048;   // ~8 elements per thread
+        at += (int)(want < 1 ? 1 : (want > (size_t)max_blocks_per_term ? (size_t)max_blocks_per_term : want));
+    }
+    a.first_block[nterms] = at;
+    a.nterms = nterms;
+    return MG_OK;
+}
+
+extern "C" size_t mg_multi_loss_scratch_floats(void) { return (size_t)MG_LOSS_MAX_TERMS * 64 + 1; }
+
+extern "C" int mg_multi_loss_fwd(const MgLossTerm *terms, int nterms, float *scratch, float *out, void *stream)
+{
+    if (!scratch || !out) return MG_ERR_ARG;
+    MultiLossArgs a;
+    MG_TRY(multi_loss_fill(a, terms, nterms, 64));
+    a.partial = scratch;
+    a.ticket = reinterpret_cast<unsigned *>(scratch + (size_t)MG_LOSS_MAX_TERMS * 64);
+    a.out = out;
+    a.g = nullptr;
+    hipLaunchKernelGGL(multi_loss_fwd_kernel, dim3(a.first_block[nterms]), dim3(256), 0, (hipStream_t)stream, a);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
+}
+
+extern "C" int mg_multi_loss_bwd(const MgLossTerm *terms, int nterms, const float *g, void *stream)
+{
+    if (!g) return MG_ERR_ARG;
+    MultiLossArgs a;
+    MG_TRY(multi_loss_fill(a, terms, nterms, 256));
+    a.partial = nullptr;
+    a.ticket = nullptr;
+    a.out = nullptr;
+    a.g = g;
+    hipLaunchKernelGGL(multi_loss_bwd_kernel, dim3(a.first_block[nterms]), dim3(256), 0, (hipStream_t)stream, a);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
+}

@@ -48,6 +48,101 @@ class _L1Fn(torch.autograd.Function):
         return d, None
 
 
+_SCRATCH = {}
+
+
+def _multi_scratch(dev):
+    """Zero-initialised once per (device, stream): the kernel keeps its ticket there and re-arms it."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    if key not in _SCRATCH:
+        _SCRATCH[key] = torch.zeros(_lib.lib().mg_multi_loss_scratch_floats(), device=dev, dtype=torch.float32)
+    return _SCRATCH[key]
+
+
+class _WeightedMeansFn(torch.autograd.Function):
+    """total = sum_k weight_k * mean_k in ONE launch (mg_multi_loss_fwd), gradients of all terms in one more.
+    spec: tuple of (mode, c, weight, group) per term, mode 0 = mean (x - c)^2, mode 1 = mean |x - y| with gradient
+    to x only; tensors: the x of every term, then the y of the mode-1 terms in order.
+    Returns the [1 + groups + nterms] result vector (total, group subtotals, per-term means); differentiate [0]."""
+
+    @staticmethod
+    def forward(ctx, spec, *tensors):
+        nt = len(spec)
+        if nt < 1 or nt > _lib.MG_LOSS_MAX_TERMS:
+            raise ValueError("1..%d terms per call" % _lib.MG_LOSS_MAX_TERMS)
+        xs = [t.contiguous() for t in tensors[:nt]]
+        ys = iter([t.detach().contiguous() for t in tensors[nt:]])
+        targets = [next(ys) if s[0] == 1 else None for s in spec]
+        terms = (_lib.LossTerm * nt)()
+        for k, (s, x, y) in enumerate(zip(spec, xs, targets)):
+            if y is not None and y.shape != x.shape:
+                raise ValueError("term %d: shapes %s vs %s" % (k, tuple(x.shape), tuple(y.shape)))
+            terms[k] = _lib.LossTerm(fptr(x).value, fptr(y, True).value if y is not None else None, None, x.numel(),
+                                     float(s[1]), float(s[2]), int(s[0]), int(s[3]))
+        dev = xs[0].device
+        out = torch.empty(1 + _lib.MG_LOSS_GROUPS + nt, device=dev, dtype=torch.float32)
+        check(_lib.lib().mg_multi_loss_fwd(terms, nt, fptr(_multi_scratch(dev)), fptr(out), stream_ptr()))
+        ctx.spec = spec
+        ctx.save_for_backward(*xs, *[y for y in targets if y is not None])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        spec, nt = ctx.spec, len(ctx.spec)
+        saved = ctx.saved_tensors
+        xs, ys = saved[:nt], iter(saved[nt:])
+        terms = (_lib.LossTerm * nt)()
+        grads = []
+        for k, (s, x) in enumerate(zip(spec, xs)):
+            y = next(ys) if s[0] == 1 else None
+            d = torch.empty_like(x) if ctx.needs_input_grad[1 + k] else None
+            grads.append(d)
+            terms[k] = _lib.LossTerm(fptr(x).value, fptr(y).value if y is not None else None,
+                                     fptr(d).value if d is not None else None, x.numel(), float(s[1]), float(s[2]),
+                                     int(s[0]), int(s[3]))
+        # only the total (element 0) is a loss; the subtotals and means are read-outs of the same numbers
+        check(_lib.lib().mg_multi_loss_bwd(terms, nt, fptr(g[:1].contiguous()), stream_ptr()))
+        return (None, *grads, *([None] * (len(saved) - nt)))
+
+
+def weighted_means(terms):
+    """terms: list of ("mse", x, c, weight[, group]) / ("l1", x, y, weight[, group]).  Returns the result vector of
+    _WeightedMeansFn: [0] total (differentiable w.r.t. every x), [1:1+4] group subtotals, then per-term means."""
+    spec, xs, ys = [], [], []
+    for t in terms:
+        kind, x, other, w = t[:4]
+        grp = t[4] if len(t) > 4 else 0
+        if kind == "mse":
+            spec.append((0, float(other), float(w), grp))
+        elif kind == "l1":
+            spec.append((1, 0.0, float(w), grp))
+            ys.append(other)
+        else:
+            raise ValueError(kind)
+        xs.append(x)
+    return _WeightedMeansFn.apply(tuple(spec), *xs, *ys)
+
+
+def d_loss_total(r_logit_cond, r_logit_uncond, f_logit_cond, f_logit_uncond):
+    """d_real + d_fake of get_lsgan_losses_fn()'s d_loss_fn (model/loss.py:12-30, train.py:142-143) as one fused sum.
+    Returns (total, d_real, d_fake); differentiate total."""
+    out = weighted_means([("mse", r_logit_cond, 1.0, 0.5, 0), ("mse", r_logit_uncond, 1.0, 0.5, 0),
+                          ("mse", f_logit_cond, 0.0, 0.5, 1), ("mse", f_logit_uncond, 0.0, 0.5, 1)])
+    return out[0], out[1], out[2]
+
+
+def g_adv_fm_total(D_real_cond, D_real_uncond, D_fake_cond, D_fake_uncond, lambda_fm, n_layers=5):
+    """adv + lambda_fm * fm of the generator loss (train.py:162-170: g_loss_fn on the last maps, get_fm_loss on the
+    others) as one fused sum.  Returns (total, adv, lambda_fm * fm); differentiate total."""
+    w = lambda_fm * (4.0 / (n_layers + 1)) * 0.5
+    terms = [("mse", D_fake_cond[-1], 1.0, 0.5, 0), ("mse", D_fake_uncond[-1], 1.0, 0.5, 0)]
+    for j in range(len(D_fake_cond) - 1):
+        terms.append(("l1", D_fake_cond[j], D_real_cond[j], w, 1))
+        terms.append(("l1", D_fake_uncond[j], D_real_uncond[j], w, 1))
+    out = weighted_means(terms)
+    return out[0], out[1], out[2]
+
+
 def _jcu_loss(logit_cond, logit_uncond, label, mask=None):
     if mask is not None:
         raise NotImplementedError("train.py never passes a mask to the adversarial losses (train.py:142,162)")

@@ -46,6 +46,9 @@ class HotPathTrainer:
         self.sdlD = torch.optim.lr_scheduler.ExponentialLR(self.optD, gamma=oc["gamma"])
         self.d_loss_fn, self.g_loss_fn = losses.get_adversarial_losses_fn(train_config["loss"]["adv_loss_mode"])
 
+    # LSGAN and feature-matching sums as one launch each way (losses.weighted_means); False keeps one launch pair per
+    # term through d_loss_fn / g_loss_fn / get_fm_loss (same values up to the order of the additions)
+    fused_losses = True
     grad_hook = None      # optional callable(name, bucket) after the gradient exchange, before clipping (tests, logging)
 
     def _update(self, params, bucket, opt):
@@ -90,18 +93,25 @@ class HotPathTrainer:
         x_ts_d, x_prevs_d, x_pp_d = x_ts.detach(), x_prevs.detach(), x_prev_preds.detach()
         spk_d = spk.detach() if spk is not None else None
         f_c, f_u, r_c, r_u = self._d_fake_and_real(x_ts_d, x_pp_d, x_prevs_d, spk_d, t)
-        d_real, d_fake = self.d_loss_fn(r_c[-1], r_u[-1], f_c[-1], f_u[-1])
-        d_loss = d_real + d_fake
+        if self.fused_losses:
+            d_loss, _, _ = losses.d_loss_total(r_c[-1], r_u[-1], f_c[-1], f_u[-1])
+        else:
+            d_real, d_fake = self.d_loss_fn(r_c[-1], r_u[-1], f_c[-1], f_u[-1])
+            d_loss = d_real + d_fake
         d_loss.backward()
         self._update(list(D.parameters()), self.bucketD, self.optD)
         # ---------------- G phase (train.py:153-184)
         x0, x_ts, x_prevs, x_prev_preds, t = G(mel, cond, spk, mel_pad_mask, coarse_mel)
         f_c, f_u, r_c, r_u = self._d_fake_and_real(x_ts, x_prev_preds, x_prevs, spk, t)
-        adv = self.g_loss_fn(f_c[-1], f_u[-1])
         target = coarse_mel.detach() if G.model == "shallow" else mel
         mel_loss = losses.get_mel_loss(G.denorm_spec(x0), target, mel_pad_mask)
-        fm = self.lambda_fm * losses.get_fm_loss(r_c, r_u, f_c, f_u, self.n_layers)
-        g_loss = adv + mel_loss + fm
+        if self.fused_losses:
+            adv_fm, adv, fm = losses.g_adv_fm_total(r_c, r_u, f_c, f_u, self.lambda_fm, self.n_layers)
+            g_loss = adv_fm + mel_loss
+        else:
+            adv = self.g_loss_fn(f_c[-1], f_u[-1])
+            fm = self.lambda_fm * losses.get_fm_loss(r_c, r_u, f_c, f_u, self.n_layers)
+            g_loss = adv + mel_loss + fm
         out = {}
         if G.model == "shallow" and coarse_mel is not None and coarse_mel.requires_grad:
             postnet_loss = losses._L1Fn.apply(coarse_mel, mel[:, :coarse_mel.shape[1], :].contiguous())

@@ -45,6 +45,20 @@ def test_losses_golden(mg):
     for k in ("fc", "fu"):
         for i in range(5):
             assert_close(dm[k][i].grad.cpu(), cm[k][i].grad, 1e-6, "%s%d grad" % (k, i))
+    # the fused sums the trainer uses (losses.weighted_means: one launch each way) against the same fixture
+    fm_ = {k: [m.cuda().requires_grad_() for m in v] for k, v in maps.items()}
+    d_tot, d_r, d_f = mg.losses.d_loss_total(fm_["rc"][-1], fm_["ru"][-1], fm_["fc"][-1], fm_["fu"][-1])
+    g_tot, adv2, fm2 = mg.losses.g_adv_fm_total(fm_["rc"], fm_["ru"], fm_["fc"], fm_["fu"], 10.0)
+    for a, ref in ((d_r, float(j["r_loss"])), (d_f, float(j["f_loss"])), (adv2, float(j["adv"])), (fm2, 10.0 * float(j["fm"])),
+                   (d_tot, float(j["r_loss"]) + float(j["f_loss"])), (g_tot, float(j["adv"]) + 10.0 * float(j["fm"]))):
+        assert abs(a.item() - ref) <= 2e-6 * max(1.0, abs(ref))
+    (d_tot + g_tot).backward()
+    for k in ("fc", "fu"):
+        for i in range(5):
+            assert_close(fm_[k][i].grad.cpu(), cm[k][i].grad, 1e-6, "fused %s%d grad" % (k, i))
+    assert all(m.grad is None for m in fm_["rc"][:-1] + fm_["ru"][:-1]), "real maps are targets of the FM term: no gradient"
+    again = mg.losses.g_adv_fm_total(fm_["rc"], fm_["ru"], fm_["fc"], fm_["fu"], 10.0)[0]
+    assert torch.equal(again, g_tot), "fixed summation order"
 
 
 def _setup(mg, manifest, tmp_path, B=3, L=40):
@@ -142,6 +156,26 @@ def test_trainer_step_runs_and_leaks_d_grads(mg, manifest, tmp_path):
     assert all(torch.isfinite(v).all() for v in out2.values())
     trainer.end_epoch()
     assert abs(trainer.optG.param_groups[0]["lr"] - 1e-4 * 0.999) < 1e-12
+
+
+def test_trainer_fused_and_per_term_losses_agree(mg, manifest, tmp_path):
+    """HotPathTrainer.fused_losses (one launch per loss sum) against the per-term path through d_loss_fn / g_loss_fn /
+    get_fm_loss: same logged losses, same gradients reaching the optimizers (the t / noise draws pinned by the seed)."""
+    seen = {}
+    for fused in (True, False):
+        G, D, WG, WD, buf, mel, cond, pad, tapes, tr, mc = _setup(mg, manifest, tmp_path)
+        trainer = mg.HotPathTrainer(G, D, tr, mc)
+        trainer.fused_losses = fused
+        grads = {}
+        trainer.grad_hook = lambda name, bucket: grads.__setitem__(name, bucket.flat.clone())
+        torch.manual_seed(5)
+        out = trainer.step(mel.cuda(), cond.cuda(), None, pad.cuda())
+        seen[fused] = (out, grads)
+    for k in ("d_loss", "adv_loss", "mel_loss", "fm_loss"):
+        a, b = seen[True][0][k].item(), seen[False][0][k].item()
+        assert abs(a - b) <= 2e-6 * max(1.0, abs(b)), k
+    for name in ("D", "G"):
+        assert_close(seen[True][1][name].cpu(), seen[False][1][name].cpu(), 2e-5, "bucket " + name)
 
 
 def test_batch_shard_gradients_average_to_the_full_batch(mg, manifest, tmp_path):
