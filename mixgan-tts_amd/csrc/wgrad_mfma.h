@@ -295,23 +295,16 @@ static int wgrad_launch(const WgradShape &s, const float *dy, const float *x, co
         const char *env = std::getenv("MG_WGRAD_STREAM");
         const bool stream_on = !(env && env[0] == '0');
         const long dybs = a.dy_bs, xbs = a.x_bs;
-        const long long units = (long long)wgrad_stream_tiles(s.Co, s.Ci, s.K, s.G) * s.B *
-                                mg_cdiv(s.Ldy, s.K == 3 ? WsCfg<3>::FT : WsCfg<1>::FT);
-        const bool ok = stream_on && s.stride == 1 && !xvec && (s.K == 1 || s.K == 3) && s.pad == (s.K - 1) / 2 &&
-                        s.Ldy == s.Lx && s.Ldy % 4 == 0 && s.Ldy >= 4 && wgrad_stream_shape_ok(s.Co, s.Ci, s.K) &&
-                        dybs % 4 == 0 && xbs % 4 == 0 && s.dy_gs % 4 == 0 && s.x_gs % 4 == 0 &&
-                        ((((uintptr_t)dy | (uintptr_t)x) & 15) == 0) &&
-                        units * 2 < (1ll << 31) &&
+        const WsShape w = wgrad_stream_shape(s.Co, s.Ci, s.K);
+        const long long units = w.cfg ? (long long)wgrad_stream_tiles(w, s.Co, s.Ci, s.G) * s.B * mg_cdiv(s.Ldy, w.FT) : 0;
+        const bool ok = stream_on && w.cfg && s.stride == 1 && !xvec && s.pad == (s.K - 1) / 2 && s.Ldy == s.Lx &&
+                        s.Ldy % 4 == 0 && s.Ldy >= 4 && dybs % 4 == 0 && xbs % 4 == 0 && s.dy_gs % 4 == 0 &&
+                        s.x_gs % 4 == 0 && ((((uintptr_t)dy | (uintptr_t)x) & 15) == 0) && units * 2 < (1ll << 31) &&
                         // at least one unit per CU; smaller gradients stay on the split kernel
                         units >= WS_NW;
-        if (ok) {
-            const long dwgs = s.dw_gs ? s.dw_gs : (long)s.Co * s.Ci * s.K;
-            if (s.K == 3)
-                return wgrad_stream_launch_k<3>(dy, x, dw, scratch, s.G, s.B, s.Co, s.Ci, s.Ldy, dybs, xbs, s.dy_gs, s.x_gs,
-                                                dwgs, alpha, accumulate, st);
-            return wgrad_stream_launch_k<1>(dy, x, dw, scratch, s.G, s.B, s.Co, s.Ci, s.Ldy, dybs, xbs, s.dy_gs, s.x_gs, dwgs,
-                                            alpha, accumulate, st);
-        }
+        if (ok)
+            return wgrad_stream_launch(w, dy, x, dw, scratch, s.G, s.B, s.Co, s.Ci, s.Ldy, dybs, xbs, s.dy_gs, s.x_gs,
+                                       s.dw_gs ? s.dw_gs : (long)s.Co * s.Ci * s.K, alpha, accumulate, st);
     }
     const bool vec = s.stride == 1 && !xvec && (s.Ldy % 4 == 0) && (s.Lx % 4 == 0) && (a.dy_bs % 4 == 0) &&
                      (a.x_bs % 4 == 0) && (a.dy_gs % 4 == 0) && (a.x_gs % 4 == 0) && ((((uintptr_t)dy | (uintptr_t)x) & 15) == 0) && s.Ldy >= 4 && s.Lx >= 4;

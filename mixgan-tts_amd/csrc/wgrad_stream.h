@@ -284,36 +284,41 @@ __global__ __launch_bounds__(256) void wgrad_stream_finalize_kernel(const float 
 static long long *ws_timing_buffer = nullptr;
 #endif
 
-// tile shapes per tap count
-template <int K> struct WsCfg;
-template <> struct WsCfg<3> { static constexpr int FT = 64, TM = 128, TN = 128, WM = 2, NI = 2, NJ = 1; };
-template <> struct WsCfg<1> { static constexpr int FT = 32, TM = 128, TN = 256, WM = 2, NI = 2, NJ = 2; };
+// Tile shapes.  k=3: 128 x 128 x 3 taps, 64-frame chunks (wave: 64 co x 32 ci x 3 taps = 6 accumulators).
+// 1x1: 128 x 256, 32-frame chunks (wave 64 x 64); when both channel counts are multiples of 256, 256 x 256 (wave
+// 64 x 128: 8 accumulators, 6 fragment reads per 8 MFMAs instead of 4 per 4, units twice as long per barrier).
+struct WsCfgK3 { static constexpr int K = 3, FT = 64, TM = 128, TN = 128, WM = 2, NI = 2, NJ = 1; };
+struct WsCfgK1 { static constexpr int K = 1, FT = 32, TM = 128, TN = 256, WM = 2, NI = 2, NJ = 2; };
+struct WsCfgK1Wide { static constexpr int K = 1, FT = 32, TM = 256, TN = 256, WM = 4, NI = 2, NJ = 4; };
 
-static inline bool wgrad_stream_shape_ok(int Co, int Ci, int K)
+struct WsShape {
+    int cfg;           // 0: not a streaming shape, 1: k=3, 2: 1x1, 3: 1x1 wide
+    int K, FT, TM, TN;
+};
+static inline WsShape wgrad_stream_shape(int Co, int Ci, int K)
 {
-    if (K == 3) return Co % WsCfg<3>::TM == 0 && Ci % WsCfg<3>::TN == 0;
-    if (K == 1) return Co % WsCfg<1>::TM == 0 && Ci % WsCfg<1>::TN == 0;
-    return false;
+    if (K == 3 && Co % WsCfgK3::TM == 0 && Ci % WsCfgK3::TN == 0) return {1, 3, WsCfgK3::FT, WsCfgK3::TM, WsCfgK3::TN};
+    if (K == 1 && Co % WsCfgK1Wide::TM == 0 && Ci % WsCfgK1Wide::TN == 0)
+        return {3, 1, WsCfgK1Wide::FT, WsCfgK1Wide::TM, WsCfgK1Wide::TN};
+    if (K == 1 && Co % WsCfgK1::TM == 0 && Ci % WsCfgK1::TN == 0) return {2, 1, WsCfgK1::FT, WsCfgK1::TM, WsCfgK1::TN};
+    return {0, K, 0, 0, 0};
 }
-static inline int wgrad_stream_tiles(int Co, int Ci, int K, int G)
-{
-    return K == 3 ? G * (Co / WsCfg<3>::TM) * (Ci / WsCfg<3>::TN) : G * (Co / WsCfg<1>::TM) * (Ci / WsCfg<1>::TN);
-}
+static inline int wgrad_stream_tiles(const WsShape &w, int Co, int Ci, int G) { return w.cfg ? G * (Co / w.TM) * (Ci / w.TN) : 0; }
 // a run of ceil(units / nw) units touches at most tiles / nw + 2 tiles
 static inline int wgrad_stream_maxseg(int tiles) { return tiles / WS_NW + 2; }
 static inline size_t wgrad_stream_scratch_floats(int Co, int Ci, int K, int G)
 {
-    if (!wgrad_stream_shape_ok(Co, Ci, K)) return 0;
-    const size_t tile = K == 3 ? (size_t)3 * WsCfg<3>::TM * WsCfg<3>::TN : (size_t)WsCfg<1>::TM * WsCfg<1>::TN;
-    return (size_t)WS_NW * wgrad_stream_maxseg(wgrad_stream_tiles(Co, Ci, K, G)) * tile;
+    const WsShape w = wgrad_stream_shape(Co, Ci, K);
+    if (!w.cfg) return 0;
+    return (size_t)WS_NW * wgrad_stream_maxseg(wgrad_stream_tiles(w, Co, Ci, G)) * w.K * w.TM * w.TN;
 }
 
-template <int K>
+template <class C>
 static int wgrad_stream_launch_k(const float *dy, const float *x, float *dw, float *scratch, int G, int B, int Co, int Ci,
                                  int L, long dy_bs, long x_bs, long dy_gs, long x_gs, long dw_gs, float alpha,
                                  int accumulate, hipStream_t st)
 {
-    using C = WsCfg<K>;
+    constexpr int K = C::K;
     WgradStreamArgs a;
     a.dy = dy;
     a.x = x;
@@ -341,4 +346,16 @@ static int wgrad_stream_launch_k(const float *dy, const float *x, float *dw, flo
                        accumulate);
     MG_LAUNCH_CHECK();
     return MG_OK;
+}
+
+static int wgrad_stream_launch(const WsShape &w, const float *dy, const float *x, float *dw, float *scratch, int G, int B,
+                               int Co, int Ci, int L, long dy_bs, long x_bs, long dy_gs, long x_gs, long dw_gs, float alpha,
+                               int accumulate, hipStream_t st)
+{
+    switch (w.cfg) {
+    case 1: return wgrad_stream_launch_k<WsCfgK3>(dy, x, dw, scratch, G, B, Co, Ci, L, dy_bs, x_bs, dy_gs, x_gs, dw_gs, alpha, accumulate, st);
+    case 2: return wgrad_stream_launch_k<WsCfgK1>(dy, x, dw, scratch, G, B, Co, Ci, L, dy_bs, x_bs, dy_gs, x_gs, dw_gs, alpha, accumulate, st);
+    case 3: return wgrad_stream_launch_k<WsCfgK1Wide>(dy, x, dw, scratch, G, B, Co, Ci, L, dy_bs, x_bs, dy_gs, x_gs, dw_gs, alpha, accumulate, st);
+    default: return MG_ERR_SHAPE;
+    }
 }
