@@ -300,8 +300,9 @@ static int wgrad_launch(const WgradShape &s, const float *dy, const float *x, co
         const bool ok = stream_on && w.cfg && s.stride == 1 && !xvec && s.pad == (s.K - 1) / 2 && s.Ldy == s.Lx &&
                         s.Ldy % 4 == 0 && s.Ldy >= 4 && dybs % 4 == 0 && xbs % 4 == 0 && s.dy_gs % 4 == 0 &&
                         s.x_gs % 4 == 0 && ((((uintptr_t)dy | (uintptr_t)x) & 15) == 0) && units * 2 < (1ll << 31) &&
-                        // at least one unit per CU; smaller gradients stay on the split kernel
-                        units >= WS_NW;
+                        // every CU flushes a whole partial tile per run: worth it from ~8 units per CU on; smaller
+                        // gradients (the skip / input / output projections) stay on the split kernel
+                        units >= 8 * WS_NW;
         if (ok)
             return wgrad_stream_launch(w, dy, x, dw, scratch, s.G, s.B, s.Co, s.Ci, s.Ldy, dybs, xbs, s.dy_gs, s.x_gs,
                                        s.dw_gs ? s.dw_gs : (long)s.Co * s.Ci * s.K, alpha, accumulate, st);

@@ -127,8 +127,8 @@ def test_denoiser_backward_vs_oracle_autograd_ragged(mg, manifest, tmp_path):
         assert_close(p.grad.cpu(), W[k].grad, 1e-4, k)
 
 
-@pytest.mark.parametrize("Ci,Co,K,B,L", [(256, 512, 3, 4, 1000), (256, 256, 1, 8, 1004), (128, 128, 3, 129, 68),
-                                         (256, 128, 1, 130, 36), (256, 640, 1, 3, 1000)])
+@pytest.mark.parametrize("Ci,Co,K,B,L", [(256, 512, 3, 16, 1000), (256, 256, 1, 64, 1004), (128, 128, 3, 1025, 68),
+                                         (256, 128, 1, 1030, 36), (256, 640, 1, 13, 1000)])
 def test_wgrad_streaming_kernel(mg, monkeypatch, Ci, Co, K, B, L):
     """Shapes the streaming kernel (wgrad_stream.h) takes: against autograd, and against the split kernel
     (MG_WGRAD_STREAM=0) that the small shapes above run on."""
@@ -152,7 +152,7 @@ def test_grouped_wgrad_streaming(mg, monkeypatch):
     """The residual stack's grouped gradients on the streaming kernel: layer slots inside wider tensors, a shared dY
     (group stride 0), alpha and accumulation; a workgroup's run of units crosses tile and group boundaries."""
     import ctypes
-    G, B, Co, Ci, K, L = 3, 6, 256, 128, 3, 520
+    G, B, Co, Ci, K, L = 3, 38, 256, 128, 3, 520
     gen = torch.Generator().manual_seed(13)
     dy_all = torch.randn(B, G * Co, L, generator=gen).cuda()
     x_all = torch.randn(G, B, Ci, L, generator=gen).cuda()
