@@ -216,21 +216,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs a)
         }
 }
 
-// scratch [nsplit][G][K][Co][Ci] -> dw[g] [Co][Ci][K] (= or +=), scaled; splits summed in index order
-__global__ void wgrad_finalize_kernel(const float *__restrict__ scratch, float *__restrict__ dw, int Co, int Ci, int K,
-                                      int G, long dw_gs, int nsplit, float alpha, int accumulate)
+// scratch [nsplit][G][K][Co][Ci] -> dw[g] [Co][Ci][K] (= or +=), scaled.  A block owns 32 consecutive scratch elements;
+// its 8 thread groups each add every 8th split (the small gradients of the discriminator run 25-128 splits: one
+// thread walking them all is a chain of that many dependent-latency loads, 15-35 us for a few hundred KB), then the
+// 8 sums are added in group order: a fixed summation order whatever the launch shape.
+__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float *__restrict__ scratch, float *__restrict__ dw,
+                                                             int Co, int Ci, int K, int G, long dw_gs, int nsplit,
+                                                             float alpha, int accumulate)
 {
+    __shared__ float part[8][32];
     const size_t per = (size_t)Co * Ci * K, n = per * G;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        // thread <-> scratch element (g, k, co, ci): coalesced reads of every split; the [Co][Ci][K] write is strided by K
-        const size_t g = i / per, r = i - g * per;
-        const size_t cc = r % ((size_t)Co * Ci);
-        const int k = (int)(r / ((size_t)Co * Ci));
-        float v = 0.f;
-        for (int s = 0; s < nsplit; ++s) v += scratch[(size_t)s * n + i];
-        v *= alpha;
-        float *o = dw + g * dw_gs + cc * K + k;
-        *o = accumulate ? *o + v : v;
+    const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    for (size_t base = (size_t)blockIdx.x * 32; base < n; base += (size_t)gridDim.x * 32) {
+        const size_t i = base + lane;
+        float v0 = 0.f, v1 = 0.f;
+        if (i < n) {
+            int s = grp;
+            for (; s + 8 < nsplit; s += 16) {
+                v0 += scratch[(size_t)s * n + i];
+                v1 += scratch[(size_t)(s + 8) * n + i];
+            }
+            if (s < nsplit) v0 += scratch[(size_t)s * n + i];
+        }
+        part[grp][lane] = v0 + v1;
+        __syncthreads();
+        if (grp == 0 && i < n) {
+            float v = part[0][lane];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) v += part[q][lane];
+            v *= alpha;
+            // scratch element (g, k, co, ci) -> dw[g][co][ci][k]: coalesced reads of every split, writes strided by K
+            const size_t g = i / per, r = i - g * per;
+            const size_t cc = r % ((size_t)Co * Ci);
+            const int k = (int)(r / ((size_t)Co * Ci));
+            float *o = dw + g * dw_gs + cc * K + k;
+            *o = accumulate ? *o + v : v;
+        }
+        __syncthreads();
     }
 }
 
@@ -312,7 +334,7 @@ static int wgrad_launch(const WgradShape &s, const float *dy, const float *x, co
     if (vec) hipLaunchKernelGGL(wgrad_mfma_kernel<true>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(wgrad_mfma_kernel<false>, grid, dim3(256), 0, st, a);
     MG_LAUNCH_CHECK();
-    const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    const int blocks = (int)((n + 31) / 32 < 8192 ? (n + 31) / 32 : 8192);
     hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, st, scratch, dw, s.Co, s.Ci, s.K, s.G,
                        s.dw_gs ? s.dw_gs : (long)s.Co * s.Ci * s.K, nsplit, alpha, accumulate);
     MG_LAUNCH_CHECK();
