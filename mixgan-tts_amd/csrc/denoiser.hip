@@ -592,13 +592,22 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
     // CUs idle: single utterances, the configs[0] shape.  Inference only; needs the 16-row packs (MG_FWD_P16).
     int nt = (long)mg_cdiv(L, 64) * B > 128 ? 64 : 32;
     if (nt == 32 && has_p16 && !save && (long)mg_cdiv(L, 32) * B <= 128) nt = 16;
-    if (const char *ne = std::getenv("MG_PERSIST_NT")) {   // tests pin each width
+    // the SAVING forward (training) on 32-frame tiles that number at most one per CU -- the per-GPU training shard,
+    // B=8, L=1000 -- runs as 8 waves of 32 channels instead of 4 of 64: the activation stores of one wave hide behind
+    // the MFMAs of its SIMD partner (measured at that shape: -0.2 ms; the non-saving forward is 8 % SLOWER that way --
+    // half the MFMAs per fragment read -- and keeps 4 waves)
+    bool wide32 = nt == 32 && save && (long)mg_cdiv(L, 32) * B <= 256;
+    if (const char *ne = std::getenv("MG_PERSIST_NT")) {   // tests pin each width: 16, 32, 64, 328 = 32 frames x 8 waves
         const int f = std::atoi(ne);
-        if (f == 32 || f == 64 || (f == 16 && has_p16 && !save)) nt = f;
+        if (f == 32 || f == 64 || f == 328 || (f == 16 && has_p16 && !save)) {
+            nt = f == 328 ? 32 : f;
+            wide32 = f == 328;
+        }
     }
     if (nt == 16 && mg_cdiv(L, 16) > 128) nt = 32;
+    if (nt != 32) wide32 = false;
     const int tiles_per_b = mg_cdiv(L, nt);
-    const int chain_cap = nt == 64 ? 64 : 128;   // a quarter of the 256 / 512 slots
+    const int chain_cap = (nt == 64 || wide32) ? 64 : 128;   // a quarter of the 256 / 512 slots
     if (fused && !no_persist && !split && M <= 96 && NL >= 3 && tiles_per_b <= chain_cap) {
         PersistArgs a;
         a.x_t = x_t;
@@ -676,6 +685,14 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
             } else if (g_persist_dbg && vec4) MG_DP_LAUNCH(64, true, true, false);
             else if (vec4) MG_DP_LAUNCH(64, true, false, false);
             else MG_DP_LAUNCH(64, false, false, false);
+        } else if (wide32) {
+#define MG_DP_LAUNCH8(V, S) hipLaunchKernelGGL((denoiser_persist_kernel<32, V, false, S, 8>), grid, dim3(512), 0, st, a)
+            if (save) {
+                if (vec4) MG_DP_LAUNCH8(true, true);
+                else MG_DP_LAUNCH8(false, true);
+            } else if (vec4) MG_DP_LAUNCH8(true, false);
+            else MG_DP_LAUNCH8(false, false);
+#undef MG_DP_LAUNCH8
         } else {
             if (save) {
                 if (vec4) MG_DP_LAUNCH(32, true, false, true);

@@ -198,11 +198,13 @@ __device__ __forceinline__ float dp_normal(unsigned long long seed, unsigned lon
 #define DP_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 #define DP_STAMP(k) do { if (TIMING && tid == 0) a.dbg[((size_t)tile * (a.NL + 2) + stamp_row) * 12 + (k)] = clock64(); } while (0)
 
-template <int NT, bool VEC4, bool TIMING = false, bool SAVE = false>
-__global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs a)
+template <int NT, bool VEC4, bool TIMING = false, bool SAVE = false, int NWV = NT / 8>
+__global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistArgs a)
 {
-    static_assert(NT == 32 || NT == 64, "tile widths: 32 (4 waves, two workgroups per CU) or 64 (8 waves, one)");
-    constexpr int NTHR = NT * 8, NW = NTHR / 64;    // threads, waves
+    static_assert((NT == 32 && (NWV == 4 || NWV == 8)) || (NT == 64 && NWV == 8),
+                  "tile widths: 32 frames (4 waves, two workgroups per CU; or 8 waves, one per CU) or 64 (8 waves, one)");
+    constexpr int NTHR = NWV * 64, NW = NWV;        // threads, waves
+    constexpr bool TWO_PER_CU = NT == 32 && NWV == 4;
     constexpr int MB = 8 / NW;                      // 32-row blocks of the 256 channels per wave: 2 (NT = 32) or 1
     constexpr int NNB = NT / 32;                    // 32-column blocks per tile
     constexpr int NC = NT, NH = NT + 2;             // columns of the cond tile and of the h tile (k-interleaved: dp_at)
@@ -222,9 +224,9 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
     // and advances in step.  Speed only: any assignment of tiles to workgroups is correct.
     const int n_tiles = a.tiles_per_b * a.B;
     const unsigned hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_REG_HW_ID; WAVE_ID = bits 3:0
-    const int role = (NT == 32 && (a.flags & DP_F_ROLES)) ? (int)(hw_id & 1u) : 0;
+    const int role = (TWO_PER_CU && (a.flags & DP_F_ROLES)) ? (int)(hw_id & 1u) : 0;
     if (tid == 0) {
-        const int nA = (NT == 32 && (a.flags & DP_F_ROLES)) ? (a.B / 2) * a.tiles_per_b : n_tiles;   // queue 0: tiles [0, nA)
+        const int nA = (TWO_PER_CU && (a.flags & DP_F_ROLES)) ? (a.B / 2) * a.tiles_per_b : n_tiles;   // queue 0: tiles [0, nA)
         const int n_mine = role == 0 ? nA : n_tiles - nA;
         unsigned tk = __hip_atomic_fetch_add(a.sync + (role ? 16 : 0), 1u, DP_RLX_AGENT);   // tickets in START order
         int tl;
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
         const float *cb = a.cond + (size_t)b * RB_C * L;
         if (VEC4) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {   // 256 rows x NT/4 float4 (frames l0 .. l0+NT-1)
+            for (int k = 0; k < 64 * NT / NTHR; ++k) {   // 256 rows x NT/4 float4 (frames l0 .. l0+NT-1)
                 const int idx = tid + k * NTHR;
                 const int row = idx / (NT / 4), c4 = idx - row * (NT / 4);
                 const int f0 = l0 + 4 * c4;
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 32; ++k) {   // 256 rows x NT frames
+            for (int k = 0; k < 256 * NT / NTHR; ++k) {   // 256 rows x NT frames
                 const int idx = tid + k * NTHR;
                 const int row = idx / NT, cc = idx - row * NT;
                 const int f = l0 + cc;
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(NT * 8, 2) void denoiser_persist_kernel(PersistArgs
         }
         const float *xb = a.x_t + (size_t)b * a.M * L;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {   // 96 rows (M = 80 padded) x NT frames -> hT channels 0..95, col c <-> frame l0+c
+        for (int k = 0; k < 96 * NT / NTHR; ++k) {   // 96 rows (M = 80 padded) x NT frames -> hT channels 0..95, col c <-> frame l0+c
             const int idx = tid + k * NTHR;
             const int row = idx / NT, c = idx - row * NT;
             const int f = l0 + c;

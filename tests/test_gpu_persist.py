@@ -30,7 +30,7 @@ def _den(mg, manifest, tmp_path, ms=False):
     return den.cuda(), W
 
 
-@pytest.mark.parametrize("nt", [16, 32, 64])
+@pytest.mark.parametrize("nt", [16, 32, 64, 328])   # 328: 32-frame tiles, 8 waves (one workgroup per CU)
 @pytest.mark.parametrize("ms", [False, True])
 def test_single_launch_forward_vs_oracle_and_per_layer_path(mg, manifest, tmp_path, monkeypatch, ms, nt):
     monkeypatch.setenv("MG_PERSIST_NT", str(nt))     # both tile widths, whatever the heuristic would pick
@@ -106,7 +106,7 @@ def test_in_kernel_noise_is_standard_normal_and_fresh(mg, manifest, tmp_path):
     assert abs(torch.corrcoef(torch.stack([za.flatten(), zb.flatten()]))[0, 1].item()) < 0.01   # a fresh stream per call
 
 
-@pytest.mark.parametrize("nt", [16, 32, 64])
+@pytest.mark.parametrize("nt", [16, 32, 64, 328])   # 328: 32-frame tiles, 8 waves (one workgroup per CU)
 def test_full_occupancy_handoffs_are_never_stale(mg, manifest, tmp_path, monkeypatch, nt):
     """B=16, L=1000: 512 workgroups, two per CU, every tile waiting on both neighbours in every layer.  The output must be
     bit-identical run after run, with or without a second stream saturating HBM beside it, and identical to what each
@@ -142,7 +142,7 @@ def test_full_occupancy_handoffs_are_never_stale(mg, manifest, tmp_path, monkeyp
     assert_close(first[:1].cpu(), ref, TOL, "vs oracle")
 
 
-@pytest.mark.parametrize("nt", [16, 32, 64])
+@pytest.mark.parametrize("nt", [16, 32, 64, 328])   # 328: 32-frame tiles, 8 waves (one workgroup per CU)
 def test_more_tiles_than_slots_and_long_utterances(mg, manifest, tmp_path, monkeypatch, nt):
     """B=40, L=1000 = 1280 (640) workgroups on 512 (256) slots (later tiles start as earlier utterances finish), and
     L=4000 (125- / 63-tile chains): finite, deterministic, equal to each sample alone."""
