@@ -12,6 +12,7 @@
 //         8a + 4h + b for lane half h, which is exactly register 4a+b of every lane, and V is read
 //         from LDS with the same key permutation.
 #include "common.h"
+#include <cstdlib>
 
 #define AT_D 128   // head dim (d_k = d_v = decoder_hidden / decoder_head = 128)
 #define AT_KT 64   // keys per LDS tile
@@ -24,7 +25,10 @@
 // Round 2: one LDS read per FOUR MFMAs (was one ds_read_b32 per MFMA), the next key tile's global loads in flight behind
 // the current tile's MFMAs (was: loaded after the barrier, fully exposed), the key mask as one ballot word per 32 keys
 // (was 16 LDS reads per block), the accumulator rescale skipped while the running maximum does not move.
-template <bool VEC>
+// KSPLIT: a 64-query workgroup whose wave pairs share the queries and split the keys of every tile (wave = 2 * query
+// group + key half), merged through LDS at the end.  Twice the workgroups for short sequences: B=16, L=1000, 2 heads is
+// 256 workgroups of 128 queries -- one per CU, one wave per SIMD, nothing to hide the staging behind.
+template <bool VEC, bool KSPLIT>
 __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const float *__restrict__ qkv,
                                                                const uint8_t *__restrict__ key_pad,
                                                                float *__restrict__ out, int L, int n_head, float scale)
@@ -36,7 +40,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const float *__re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, r = lane & 31;
     const int b = blockIdx.z, head = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = KSPLIT ? blockIdx.x * 64 + (wave >> 1) * 32 : blockIdx.x * 128 + wave * 32;
     const int HD = n_head * AT_D;
     const float *Q = qkv + ((size_t)b * 3 * HD + head * AT_D) * L;
     const float *K = Q + (size_t)HD * L;
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const float *__re
         __syncthreads();
         if (kt0 + AT_KT < L) load_tile(kt0 + AT_KT);   // flies behind the 256 MFMAs below
 #pragma unroll
-        for (int kb = 0; kb < AT_KT / 32; ++kb) {
+        for (int kb = KSPLIT ? (wave & 1) : 0; kb < (KSPLIT ? (wave & 1) + 1 : AT_KT / 32); ++kb) {
             f32x16 S;
 #pragma unroll
             for (int j = 0; j < 16; ++j) S[j] = 0.f;
@@ -172,6 +176,30 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const float *__re
                         O[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[i][bq], S[4 * aa + bq], O[i], 0, 0, 0);
             }
         }
+    }
+    if (KSPLIT) {
+        // merge the two key halves of a query group: the odd wave parks (m, l, O) in the K tile's storage
+        // (2 query groups x 64 lanes x 66 floats = the tile's 8448 floats exactly)
+        __syncthreads();   // the last tile is consumed
+        float *park = Kt + ((wave >> 1) * 64 + lane) * 66;
+        if (wave & 1) {
+            park[0] = m_run;
+            park[1] = l_run;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) park[2 + 16 * i + j] = O[i][j];
+        }
+        __syncthreads();
+        if (wave & 1) return;
+        const float m1 = park[0], l1 = park[1];
+        const float m = fmaxf(m_run, m1);
+        const float c0 = __expf(m_run - m), c1 = __expf(m1 - m);
+        l_run = l_run * c0 + l1 * c1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) O[i][j] = O[i][j] * c0 + park[2 + 16 * i + j] * c1;
     }
     const int q = q0 + r;
     if (q < L) {
@@ -389,10 +417,19 @@ extern "C" int mg_attention_fwd(const float *qkv, const uint8_t *key_pad, float 
 {
     if (!qkv || !out) return MG_ERR_ARG;
     if (B <= 0 || L <= 0 || n_head <= 0 || d_head != AT_D) return MG_ERR_SHAPE;
-    dim3 grid(mg_cdiv(L, 128), n_head, B);
     const bool vec = (L % 4 == 0) && (((uintptr_t)qkv & 15) == 0);
-    if (vec) hipLaunchKernelGGL(attention_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, qkv, key_pad, out, L, n_head, scale);
-    else hipLaunchKernelGGL(attention_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, qkv, key_pad, out, L, n_head, scale);
+    // fewer than two 128-query workgroups per CU: 64-query workgroups that split the keys between wave pairs
+    const char *ke = std::getenv("MG_ATTENTION_KSPLIT");   // tests pin each form
+    const bool ksplit = ke ? ke[0] == '1' : (long)mg_cdiv(L, 128) * n_head * B < 512;
+    dim3 grid(mg_cdiv(L, ksplit ? 64 : 128), n_head, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (ksplit) {
+        if (vec) hipLaunchKernelGGL((attention_fwd_kernel<true, true>), grid, dim3(256), 0, st, qkv, key_pad, out, L, n_head, scale);
+        else hipLaunchKernelGGL((attention_fwd_kernel<false, true>), grid, dim3(256), 0, st, qkv, key_pad, out, L, n_head, scale);
+    } else {
+        if (vec) hipLaunchKernelGGL((attention_fwd_kernel<true, false>), grid, dim3(256), 0, st, qkv, key_pad, out, L, n_head, scale);
+        else hipLaunchKernelGGL((attention_fwd_kernel<false, false>), grid, dim3(256), 0, st, qkv, key_pad, out, L, n_head, scale);
+    }
     MG_LAUNCH_CHECK();
     return MG_OK;
 }

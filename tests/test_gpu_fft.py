@@ -50,8 +50,10 @@ def test_decoder_and_postnet_golden(mg, manifest):
     assert_close(pn(dev(g["x"])).cpu(), g["out"], TOL, "PostNet")
 
 
+@pytest.mark.parametrize("ksplit", ["0", "1"])   # 128-query workgroups / 64-query workgroups that split the keys
 @pytest.mark.parametrize("B,L,lens", [(2, 300, [300, 171]), (3, 64, [64, 1, 33]), (1, 129, [129])])
-def test_attention_and_layernorm_vs_oracle(mg, manifest, B, L, lens):
+def test_attention_and_layernorm_vs_oracle(mg, manifest, monkeypatch, B, L, lens, ksplit):
+    monkeypatch.setenv("MG_ATTENTION_KSPLIT", ksplit)
     W, _ = seeded(manifest, "fftblock", 99)
     gen = torch.Generator().manual_seed(L)
     x = torch.randn(B, L, 256, generator=gen)
