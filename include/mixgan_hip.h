@@ -98,6 +98,12 @@ size_t mg_conv1d_wgrad_grouped_scratch_floats(int Co, int Ci, int K, int G);
 int mg_conv1d_wgrad_grouped(const float *dy, long dy_bs, long dy_gs, const float *x, long x_bs, long x_gs, float *dw,
                             long dw_gs, float *scratch, int G, int B, int Co, int Ci, int Ldy, int Lx, int K, int stride,
                             int pad, float alpha, int accumulate, void *stream);
+/* ... and the bias gradients with it: db[g][co] (+)= alpha * sum_{b,l} dy_g[b,co,l] (group stride db_gs, 0 -> Co).
+ * The streaming kernel (large stride-1 "same" shapes) sums the dY rows while it stages them; other shapes fall back
+ * to one mg_rowsum launch per group.  Same scratch as mg_conv1d_wgrad_grouped. */
+int mg_conv1d_wgrad_grouped_bias(const float *dy, long dy_bs, long dy_gs, const float *x, long x_bs, long x_gs, float *dw,
+                                 long dw_gs, float *db, long db_gs, float *scratch, int G, int B, int Co, int Ci, int Ldy,
+                                 int Lx, int K, int stride, int pad, float alpha, int accumulate, void *stream);
 
 /* Row sums of in [B,R,L] (batch stride in_bs floats, 0 = dense): bias gradients and per-sample
  * channel sums.  out_r[r] (+)= alpha*sum_{b,l} (may be NULL); out_br[b,r] = alpha*sum_l (may be NULL). */

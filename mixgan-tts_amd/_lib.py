@@ -14,7 +14,7 @@ EXPORTS = (
     "mg_upsample_zero_act", "mg_diffuse_trace_bwd", "mg_bgemm", "mg_softmax_rows_fwd", "mg_softmax_rows_bwd", "mg_layernorm_cm_train_fwd",
     "mg_layernorm_cm_bwd", "mg_bn_stats", "mg_bn_act_fwd", "mg_bn_act_bwd_reduce", "mg_bn_act_bwd_apply", "mg_conv_transpose_packed_floats", "mg_conv_transpose_pack", "mg_conv_transpose1d_fwd",
     "mg_conv1d_wgrad_scratch_floats", "mg_conv1d_wgrad", "mg_conv1d_wgrad_strided", "mg_conv1d_wgrad_grouped",
-    "mg_conv1d_wgrad_grouped_scratch_floats", "mg_rowsum",
+    "mg_conv1d_wgrad_grouped_scratch_floats", "mg_conv1d_wgrad_grouped_bias", "mg_rowsum",
     "mg_diffuse_fwd", "mg_posterior_sample_fwd", "mg_posterior_sample_bwd", "mg_spec_affine", "mg_transpose_bml",
     "mg_denoiser_packed_floats", "mg_denoiser_pack", "mg_denoiser_workspace_floats", "mg_denoiser_fwd",
     "mg_denoiser_bwd_workspace_floats", "mg_denoiser_bwd",
@@ -111,6 +111,7 @@ def _declare(L):
         "mg_rowsum": (i, [vp, ctypes.c_long, i, i, i, vp, vp, f, i, vp]),
         "mg_conv1d_wgrad_grouped_scratch_floats": (sz, [i, i, i, i]),
         "mg_conv1d_wgrad_grouped": (i, [vp, lg, lg, vp, lg, lg, vp, lg, vp, i, i, i, i, i, i, i, i, i, f, i, vp]),
+        "mg_conv1d_wgrad_grouped_bias": (i, [vp, lg, lg, vp, lg, lg, vp, lg, vp, lg, vp, i, i, i, i, i, i, i, i, i, f, i, vp]),
         "mg_denoiser_packed_floats": (sz, [dp, i]),
         "mg_denoiser_pack": (i, [dp, vp, vp, vp, i, vp]),
         "mg_denoiser_bwd_workspace_floats": (sz, [dp, i, i]),

@@ -141,6 +141,28 @@ extern "C" int mg_conv1d_wgrad_grouped(const float *dy, long dy_bs, long dy_gs, 
     return wgrad_launch(s, dy, x, nullptr, dw, scratch, alpha, accumulate, (hipStream_t)stream);
 }
 
+extern "C" int mg_rowsum(const float *in, long in_bs, int B, int R, int L, float *out_r, float *out_br, float alpha,
+                         int accumulate, void *stream);
+
+extern "C" int mg_conv1d_wgrad_grouped_bias(const float *dy, long dy_bs, long dy_gs, const float *x, long x_bs, long x_gs,
+                                            float *dw, long dw_gs, float *db, long db_gs, float *scratch, int G, int B,
+                                            int Co, int Ci, int Ldy, int Lx, int K, int stride, int pad, float alpha,
+                                            int accumulate, void *stream)
+{
+    if (!dy || !x || !dw || !db || !scratch) return MG_ERR_ARG;
+    if (stride < 1 || pad < 0 || G < 1) return MG_ERR_SHAPE;
+    bool done = false;
+    WgradShape s{B, Co, Ci, Ldy, Lx, K, stride, pad, dy_bs, x_bs, G, dy_gs, x_gs, dw_gs, db, db_gs, &done};
+    MG_TRY(wgrad_launch(s, dy, x, nullptr, dw, scratch, alpha, accumulate, (hipStream_t)stream));
+    if (!done) {   // the split kernel ran (small or unaligned shapes): one row-sum launch per group
+        const long bs = dy_bs ? dy_bs : (long)Co * Ldy;
+        for (int g = 0; g < G; ++g)
+            MG_TRY(mg_rowsum(dy + (size_t)g * dy_gs, bs, B, Co, Ldy, db + (size_t)g * (db_gs ? db_gs : Co), nullptr, alpha,
+                             accumulate, stream));
+    }
+    return MG_OK;
+}
+
 extern "C" int mg_conv1d_wgrad(const float *dy, const float *x, const float *x_vec, float *dw, float *scratch, int B,
                                int Co, int Ci, int Ldy, int Lx, int K, int stride, int pad, float alpha,
                                int accumulate, void *stream)

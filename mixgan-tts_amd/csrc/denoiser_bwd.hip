@@ -144,9 +144,14 @@ static int wgrad_launch(const WgradShape &s, const float *dy, const float *x, co
                                    s.pad, alpha, accumulate, st);
 }
 
+// db (optional): the bias gradients [G][db_gs] from the same pass over dy
 static int wgrad_grouped(int G, const float *dy, long dy_bs, long dy_gs, const float *x, long x_bs, long x_gs, float *dw,
-                         long dw_gs, float *scratch, int B, int Co, int Ci, int L, int K, int pad, hipStream_t st)
+                         long dw_gs, float *scratch, int B, int Co, int Ci, int L, int K, int pad, hipStream_t st,
+                         float *db = nullptr, long db_gs = 0)
 {
+    if (db)
+        return mg_conv1d_wgrad_grouped_bias(dy, dy_bs, dy_gs, x, x_bs, x_gs, dw, dw_gs, db, db_gs, scratch, G, B, Co, Ci, L, L,
+                                            K, 1, pad, 1.f, 0, st);
     return mg_conv1d_wgrad_grouped(dy, dy_bs, dy_gs, x, x_bs, x_gs, dw, dw_gs, scratch, G, B, Co, Ci, L, L, K, 1, pad, 1.f,
                                    0, st);
 }
@@ -292,17 +297,20 @@ extern "C" int mg_denoiser_bwd(const mg_denoiser_dims *d, const float *packed, c
     {
         const float *h_all = ws + w.h, *g_all = ws + w.g;
         const long act_gs = (long)w.act_stride;
-        if (LG(0, 0))   // k=3 conv: dW3_l = dz_l (*) h_l
+        // The bias gradients (row sums of dz, of the dx slots and of dskip over batch and frames) come out of the
+        // weight-gradient launches that read those rows anyway (mg_conv1d_wgrad_grouped_bias).
+        const bool fold3 = LG(0, 0) && LG(0, 1), foldo = LG(0, 5) && LG(0, 6);
+        if (LG(0, 0))   // k=3 conv: dW3_l = dz_l (*) h_l;  db3_l = rowsum(dz_l)
             MG_TRY(wgrad_grouped(NL, dz_all, dz_bs, (long)(2 * CL), h_all, (long)CL, act_gs, LG(0, 0), (long)2 * C * C * 3, scr,
-                                 B, 2 * C, C, L, 3, 1, st));
-        if (LG(0, 1)) MG_TRY(rowsum(dz_all, 0, B, NL * 2 * C, L, LG(0, 1), nullptr, 1.f, st));
+                                 B, 2 * C, C, L, 3, 1, st, fold3 ? LG(0, 1) : nullptr, (long)(2 * C)));
+        if (LG(0, 1) && !fold3) MG_TRY(rowsum(dz_all, 0, B, NL * 2 * C, L, LG(0, 1), nullptr, 1.f, st));
         if (LG(0, 5)) {   // output conv: rows < C see dx_l (slot l+1), rows >= C the layer-independent dskip
             MG_TRY(wgrad_grouped(NL, dx_all + CL, dx_bs, (long)CL, g_all, (long)CL, act_gs, LG(0, 5), (long)2 * C * C, scr, B, C,
-                                 C, L, 1, 0, st));
+                                 C, L, 1, 0, st, foldo ? LG(0, 6) : nullptr, (long)(2 * C)));
             MG_TRY(wgrad_grouped(NL, dout + CL, (long)(2 * CL), 0, g_all, (long)CL, act_gs, LG(0, 5) + (size_t)C * C,
-                                 (long)2 * C * C, scr, B, C, C, L, 1, 0, st));
+                                 (long)2 * C * C, scr, B, C, C, L, 1, 0, st, foldo ? LG(0, 6) + C : nullptr, (long)(2 * C)));
         }
-        if (LG(0, 6)) {
+        if (LG(0, 6) && !foldo) {
             MG_TRY(rowsum(dx_all + CL, dx_bs, B, NL * C, L, bws + bw.btop, nullptr, 1.f, st));
             MG_TRY(rowsum(dout + CL, (long)(2 * CL), B, C, L, bws + bw.bbot, nullptr, 1.f, st));
             hipLaunchKernelGGL(bias_scatter_kernel, dim3(mg_cdiv(NL * 2 * C, 256)), dim3(256), 0, st, bws + bw.btop,
@@ -339,11 +347,19 @@ extern "C" int mg_denoiser_bwd(const mg_denoiser_dims *d, const float *packed, c
         EpiBiasAct::Params ep{d_cond, nullptr, nullptr, 1.f, H, MG_ACT_NONE, 0, 0, nullptr, 0.f};
         MG_TRY(conv_launch<EpiBiasAct>(s, dh_all, nullptr, packed + o.wc_allT, ep, st));
     }
+    // single-speaker: the bias gradients rowsum(dh) ride on the weight-gradient launch; multi-speaker needs the
+    // per-sample sums too (the speaker vector enters h), which stay one row-sum launch that yields both
+    const bool foldc = LG(0, 3) && LG(0, 4) && !d->multi_speaker;
     if (LG(0, 3)) {
-        WgradShape s{B, NL * C, H, L, L, 1, 1, 0, 0, 0};
-        MG_TRY(wgrad_launch(s, dh_all, cond, nullptr, LG(0, 3), scr, 1.f, 0, st));
+        if (foldc) {
+            MG_TRY(mg_conv1d_wgrad_grouped_bias(dh_all, 0, 0, cond, 0, 0, LG(0, 3), 0, LG(0, 4), 0, scr, 1, B, NL * C, H, L, L, 1,
+                                                1, 0, 1.f, 0, st));
+        } else {
+            WgradShape s{B, NL * C, H, L, L, 1, 1, 0, 0, 0};
+            MG_TRY(wgrad_launch(s, dh_all, cond, nullptr, LG(0, 3), scr, 1.f, 0, st));
+        }
     }
-    if (LG(0, 4) || d->multi_speaker)
+    if ((LG(0, 4) && !foldc) || d->multi_speaker)
         MG_TRY(rowsum(dh_all, 0, B, NL * C, L, LG(0, 4), d->multi_speaker ? bws + bw.dhv_all : nullptr, 1.f, st));
 
     // ---- step-embedding MLP and per-layer step / speaker projections (tiny, per sample) --------

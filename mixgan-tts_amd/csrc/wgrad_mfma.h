@@ -281,6 +281,11 @@ struct WgradShape {
     long dy_bs, x_bs;  // 0 -> dense
     int G = 1;         // groups (see WgradArgs)
     long dy_gs = 0, x_gs = 0, dw_gs = 0;
+    // optional bias gradient db[g][co] = alpha * sum_{b,l} dY_g[b, co, l] (group stride db_gs, 0 -> Co): the streaming
+    // kernel produces it on the way; *db_done tells the caller whether it did (otherwise: a row-sum launch)
+    float *db = nullptr;
+    long db_gs = 0;
+    bool *db_done = nullptr;
 };
 
 static int wgrad_launch(const WgradShape &s, const float *dy, const float *x, const float *xvec, float *dw,
@@ -325,9 +330,11 @@ static int wgrad_launch(const WgradShape &s, const float *dy, const float *x, co
                         // every CU flushes a whole partial tile per run: worth it from ~8 units per CU on; smaller
                         // gradients (the skip / input / output projections) stay on the split kernel
                         units >= 8 * WS_NW;
-        if (ok)
+        if (ok) {
+            if (s.db_done) *s.db_done = s.db != nullptr;
             return wgrad_stream_launch(w, dy, x, dw, scratch, s.G, s.B, s.Co, s.Ci, s.Ldy, dybs, xbs, s.dy_gs, s.x_gs,
-                                       s.dw_gs ? s.dw_gs : (long)s.Co * s.Ci * s.K, alpha, accumulate, st);
+                                       s.dw_gs ? s.dw_gs : (long)s.Co * s.Ci * s.K, alpha, accumulate, st, s.db, s.db_gs);
+        }
     }
     const bool vec = s.stride == 1 && !xvec && (s.Ldy % 4 == 0) && (s.Lx % 4 == 0) && (a.dy_bs % 4 == 0) &&
                      (a.x_bs % 4 == 0) && (a.dy_gs % 4 == 0) && (a.x_gs % 4 == 0) && ((((uintptr_t)dy | (uintptr_t)x) & 15) == 0) && s.Ldy >= 4 && s.Lx >= 4;

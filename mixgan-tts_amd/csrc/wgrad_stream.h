@@ -28,6 +28,7 @@ struct WgradStreamArgs {
     int co_tiles, ci_tiles, chunks_per_b, nchunks;
     unsigned units;    // tiles * nchunks
     int maxseg;
+    float *rs_part;    // optional [nw][maxseg][TM]: partial row sums of dY (bias gradients) from the ci-tile-0 tiles
 #ifdef WS_TIMING
     long long *dbg;    // [nw][8 waves][4]: cycles in (load issue, MFMA loop, LDS store + flush, barrier); tools/ubench only
 #endif
@@ -98,6 +99,26 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(WgradStreamArgs a)
     f32x4 va[NA], vb[NB];
     unsigned okA = 0, okB = 0;   // which staged elements are inside [0, L): applied when the registers go to LDS
     const int tiles_per_g = a.co_tiles * a.ci_tiles;
+    // Bias gradients ride along: every dY element passes through this thread's registers on its way to LDS, so the
+    // row sums of dY over (batch, frames) cost four adds per staged float4.  Tiles with ci-tile 0 count (the others
+    // stage the same rows again); the sums follow the STAGED stream, which runs one unit ahead of the MFMAs.
+    float rs[NA];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) rs[k] = 0.f;
+    bool rs_on = false;   // the staged tile contributes row sums
+    int rs_seg = 0;       // segment (tile index within this workgroup's run) of the staged tile
+    auto rs_flush = [&]() {
+        if (!a.rs_part) return;
+        float *dst = a.rs_part + ((size_t)blockIdx.x * a.maxseg + rs_seg) * TM;
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            float v = rs[k];
+#pragma unroll
+            for (int o = A4 / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);   // the A4 lanes that share a row
+            if (c4A == 0) dst[tid / A4 + k * RA] = rs_on ? v : 0.f;
+            rs[k] = 0.f;
+        }
+    };
 
     // The staging of unit u+1 is spread over the k-steps of unit u: ONE global load per k-step at the front of the
     // loop (a burst of all of them right after the barrier, from all eight waves at once, backs up the memory pipe and
@@ -108,6 +129,7 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(WgradStreamArgs a)
     auto set_tile = [&](int tile) {   // wave-uniform; the divisions run once per tile, not once per unit
         const int g = tile / tiles_per_g, r = tile - g * tiles_per_g;
         const int cot = r / a.ci_tiles, cit = r - cot * a.ci_tiles;
+        rs_on = cit == 0;
         dyt = a.dy + (size_t)g * a.dy_gs + (size_t)cot * TM * a.L;
         xt = a.x + (size_t)g * a.x_gs + (size_t)cit * TN * a.L;
     };
@@ -127,10 +149,11 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(WgradStreamArgs a)
             if (f >= 0 && f < a.L) okB |= 1u << k;
         }
     };
-    auto store_elem = [&](float *buf, int e) {
+    auto store_elem = [&](float *buf, int e, bool count) {
         if (e < NA) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) buf[lA0 + e * RA * RSA + j] = okA ? va[e][j] : 0.f;
+            if (count && okA) rs[e] += (va[e][0] + va[e][1]) + (va[e][2] + va[e][3]);
         } else {
             const int k = e - NA;
             if (k + 1 < NB || TN * B4 % 512 == 0 || tid + k * 512 < TN * B4) {
@@ -165,7 +188,7 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(WgradStreamArgs a)
 #pragma unroll
     for (int e = 0; e < NE; ++e) load_elem(e);
 #pragma unroll
-    for (int e = 0; e < NE; ++e) store_elem(lds, e);
+    for (int e = 0; e < NE; ++e) store_elem(lds, e, true);
     __syncthreads();
     const int offA = (wm * NI * 32 + c32) * RSA + hh;
     const int offB = TM * RSA + (wn * NJ * 32 + c32) * RSB + hh + (K == 3 ? 3 : 0);
@@ -186,6 +209,8 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(WgradStreamArgs a)
                 sc = 0;
                 if (++sb == a.nchunks / a.chunks_per_b) {
                     sb = 0;
+                    rs_flush();   // every unit of the previous tile has been staged
+                    ++rs_seg;
                     set_tile(ntile);
                 }
             }
@@ -211,7 +236,7 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(WgradStreamArgs a)
             const int q = s & 1;
             if (s + 1 < NS) frags(s + 1, q ^ 1);
             if (s < NE) load_elem(s);
-            if (s >= NS / 2 && s - NS / 2 < NE) store_elem(nbuf, s - NS / 2);
+            if (s >= NS / 2 && s - NS / 2 < NE) store_elem(nbuf, s - NS / 2, more);   // !more: a dummy restage
 #pragma unroll
             for (int t = 0; t < K; ++t)
 #pragma unroll
@@ -234,6 +259,7 @@ __global__ __launch_bounds__(512) void wgrad_stream_kernel(WgradStreamArgs a)
         tile = ntile;
         chunk = nchunk;
     }
+    rs_flush();
 #ifdef WS_TIMING
     if (lane == 0)
         for (int k = 0; k < 4; ++k) a.dbg[((size_t)blockIdx.x * 8 + wave) * 4 + k] = tacc[k];
@@ -284,6 +310,33 @@ __global__ __launch_bounds__(256) void wgrad_stream_finalize_kernel(const float 
 static long long *ws_timing_buffer = nullptr;
 #endif
 
+// partial row sums -> db[g][co] (= or +=), scaled: one thread per output row, the contributing workgroups (those whose
+// run touched the row's ci-tile-0 tile) added in index order
+template <int TM>
+__global__ __launch_bounds__(256) void wgrad_stream_rowsum_finalize_kernel(const float *__restrict__ rs_part,
+                                                                           float *__restrict__ db, int Co, int G,
+                                                                           int co_tiles, int ci_tiles, int nchunks,
+                                                                           unsigned units, unsigned nw, int maxseg,
+                                                                           long db_gs, float alpha, int accumulate)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= G * Co) return;
+    const int g = i / Co, co = i - g * Co;
+    const int tile = (g * co_tiles + co / TM) * ci_tiles;
+    const unsigned a0 = (unsigned)tile * nchunks, a1 = a0 + nchunks;
+    unsigned w = (unsigned)(((unsigned long long)a0 * nw) / units);
+    while (w + 1 < nw && ws_start(w + 1, units, nw) <= a0) ++w;
+    float v = 0.f;
+    for (; w < nw; ++w) {
+        const unsigned s0 = ws_start(w, units, nw);
+        if (s0 >= a1) break;
+        const int seg = tile - (int)(s0 / (unsigned)nchunks);
+        v += rs_part[((size_t)w * maxseg + seg) * TM + co % TM];
+    }
+    float *o = db + (size_t)g * db_gs + co;
+    *o = accumulate ? *o + alpha * v : alpha * v;
+}
+
 // Tile shapes.  k=3: 128 x 128 x 3 taps, 64-frame chunks (wave: 64 co x 32 ci x 3 taps = 6 accumulators).
 // 1x1: 128 x 256, 32-frame chunks (wave 64 x 64); when both channel counts are multiples of 256, 256 x 256 (wave
 // 64 x 128: 8 accumulators, 6 fragment reads per 8 MFMAs instead of 4 per 4, units twice as long per barrier).
@@ -310,13 +363,14 @@ static inline size_t wgrad_stream_scratch_floats(int Co, int Ci, int K, int G)
 {
     const WsShape w = wgrad_stream_shape(Co, Ci, K);
     if (!w.cfg) return 0;
-    return (size_t)WS_NW * wgrad_stream_maxseg(wgrad_stream_tiles(w, Co, Ci, G)) * w.K * w.TM * w.TN;
+    // partial tiles + partial row sums (the optional bias gradients)
+    return (size_t)WS_NW * wgrad_stream_maxseg(wgrad_stream_tiles(w, Co, Ci, G)) * ((size_t)w.K * w.TM * w.TN + w.TM);
 }
 
 template <class C>
 static int wgrad_stream_launch_k(const float *dy, const float *x, float *dw, float *scratch, int G, int B, int Co, int Ci,
                                  int L, long dy_bs, long x_bs, long dy_gs, long x_gs, long dw_gs, float alpha,
-                                 int accumulate, hipStream_t st)
+                                 int accumulate, hipStream_t st, float *db = nullptr, long db_gs = 0)
 {
     constexpr int K = C::K;
     WgradStreamArgs a;
@@ -336,6 +390,7 @@ static int wgrad_stream_launch_k(const float *dy, const float *x, float *dw, flo
     a.units = (unsigned)tiles * (unsigned)a.nchunks;
     a.maxseg = wgrad_stream_maxseg(tiles);
     const unsigned nw = a.units < WS_NW ? a.units : WS_NW;
+    a.rs_part = db ? scratch + (size_t)WS_NW * a.maxseg * K * C::TM * C::TN : nullptr;
 #ifdef WS_TIMING
     a.dbg = ws_timing_buffer;
 #endif
@@ -345,17 +400,23 @@ static int wgrad_stream_launch_k(const float *dy, const float *x, float *dw, flo
                        0, st, scratch, dw, Ci, a.co_tiles, a.ci_tiles, a.nchunks, a.units, nw, a.maxseg, dw_gs, alpha,
                        accumulate);
     MG_LAUNCH_CHECK();
+    if (db) {
+        hipLaunchKernelGGL((wgrad_stream_rowsum_finalize_kernel<C::TM>), dim3((unsigned)mg_cdiv(G * Co, 256)), dim3(256), 0,
+                           st, a.rs_part, db, Co, G, a.co_tiles, a.ci_tiles, a.nchunks, a.units, nw, a.maxseg,
+                           db_gs ? db_gs : (long)Co, alpha, accumulate);
+        MG_LAUNCH_CHECK();
+    }
     return MG_OK;
 }
 
 static int wgrad_stream_launch(const WsShape &w, const float *dy, const float *x, float *dw, float *scratch, int G, int B,
                                int Co, int Ci, int L, long dy_bs, long x_bs, long dy_gs, long x_gs, long dw_gs, float alpha,
-                               int accumulate, hipStream_t st)
+                               int accumulate, hipStream_t st, float *db = nullptr, long db_gs = 0)
 {
     switch (w.cfg) {
-    case 1: return wgrad_stream_launch_k<WsCfgK3>(dy, x, dw, scratch, G, B, Co, Ci, L, dy_bs, x_bs, dy_gs, x_gs, dw_gs, alpha, accumulate, st);
-    case 2: return wgrad_stream_launch_k<WsCfgK1>(dy, x, dw, scratch, G, B, Co, Ci, L, dy_bs, x_bs, dy_gs, x_gs, dw_gs, alpha, accumulate, st);
-    case 3: return wgrad_stream_launch_k<WsCfgK1Wide>(dy, x, dw, scratch, G, B, Co, Ci, L, dy_bs, x_bs, dy_gs, x_gs, dw_gs, alpha, accumulate, st);
+    case 1: return wgrad_stream_launch_k<WsCfgK3>(dy, x, dw, scratch, G, B, Co, Ci, L, dy_bs, x_bs, dy_gs, x_gs, dw_gs, alpha, accumulate, st, db, db_gs);
+    case 2: return wgrad_stream_launch_k<WsCfgK1>(dy, x, dw, scratch, G, B, Co, Ci, L, dy_bs, x_bs, dy_gs, x_gs, dw_gs, alpha, accumulate, st, db, db_gs);
+    case 3: return wgrad_stream_launch_k<WsCfgK1Wide>(dy, x, dw, scratch, G, B, Co, Ci, L, dy_bs, x_bs, dy_gs, x_gs, dw_gs, alpha, accumulate, st, db, db_gs);
     default: return MG_ERR_SHAPE;
     }
 }

@@ -178,6 +178,33 @@ def test_grouped_wgrad_streaming(mg, monkeypatch):
     assert_close(dw[1].cpu(), w.grad, 2e-5, "grouped streaming wgrad vs autograd")
 
 
+def test_grouped_wgrad_bias_rides_along(mg, monkeypatch):
+    """mg_conv1d_wgrad_grouped_bias: db[g][co] = sum_{b,l} dy_g -- from the streaming kernel's staging registers for the
+    shapes it takes, from row-sum launches otherwise; shared dY (group stride 0), a strided db, alpha, accumulation."""
+    import ctypes
+    lib = mg._lib.lib()
+    cp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    gen = torch.Generator().manual_seed(14)
+    for (G, B, Co, Ci, K, L, dy_shared) in [(3, 38, 256, 128, 3, 520, False), (2, 64, 256, 256, 1, 1004, True),
+                                           (2, 3, 96, 40, 3, 204, False)]:
+        dy_all = torch.randn(B, G * Co, L, generator=gen).cuda()
+        x_all = torch.randn(G, B, Ci, L, generator=gen).cuda()
+        scratch = torch.empty(lib.mg_conv1d_wgrad_grouped_scratch_floats(Co, Ci, K, G), device="cuda")
+        dy_gs = 0 if dy_shared else Co * L
+        dbs = 2 * Co                                   # bias rows of a group sit inside a wider row (the [2C] output-conv bias)
+        for stream in ("1", "0"):
+            monkeypatch.setenv("MG_WGRAD_STREAM", stream)
+            dw = torch.empty(G, Co, Ci, K, device="cuda")
+            db = torch.full((G, dbs), 7.0, device="cuda")
+            mg._lib.check(lib.mg_conv1d_wgrad_grouped_bias(cp(dy_all), G * Co * L, dy_gs, cp(x_all), Ci * L, B * Ci * L, cp(dw), 0,
+                                                           cp(db), dbs, cp(scratch), G, B, Co, Ci, L, L, K, 1, (K - 1) // 2, 0.5, 1, None))
+            for g in range(G):
+                rows = dy_all[:, :Co] if dy_shared else dy_all[:, g * Co:(g + 1) * Co]
+                ref = 7.0 + 0.5 * rows.double().sum((0, 2))
+                assert_close(db[g, :Co].cpu(), ref.float().cpu(), 2e-5, "bias gradient, group %d, stream=%s" % (g, stream))
+                assert torch.all(db[g, Co:] == 7.0), "rows outside the group's bias slice were written"
+
+
 def test_grouped_wgrad_matches_per_group_calls(mg):
     """mg_conv1d_wgrad_grouped: G gradients of one shape in one launch (shared or per-group operands, strided
     slots inside wider tensors) == G separate mg_conv1d_wgrad calls."""

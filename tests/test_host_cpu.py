@@ -46,10 +46,10 @@ def test_error_strings_and_arg_checks():
     assert L.mg_diffuse_trace_bwd(None, None, None, None, None, None, None, 4, 1, 4, 80, None) == -1
     # streaming kernel (wgrad_stream.h): 256 workgroups x (tiles / 256 + 2) partial tiles of K x 128 x 128 (k=3) or
     # 128 x 256 (k=1); shapes it does not take keep the split kernel's [nsplit][G][K][Co][Ci]
-    assert L.mg_conv1d_wgrad_grouped_scratch_floats(512, 256, 3, 20) == 256 * 2 * 3 * 128 * 128
-    assert L.mg_conv1d_wgrad_grouped_scratch_floats(256, 256, 1, 20) == 256 * 2 * 256 * 256      # 1x1 wide tiles
-    assert L.mg_conv1d_wgrad_grouped_scratch_floats(128, 256, 1, 20) == 256 * 2 * 128 * 256
-    assert L.mg_conv1d_wgrad_grouped_scratch_floats(512, 256, 3, 400) == 256 * (3200 // 256 + 2) * 3 * 128 * 128
+    assert L.mg_conv1d_wgrad_grouped_scratch_floats(512, 256, 3, 20) == 256 * 2 * (3 * 128 * 128 + 128)   # + partial row sums
+    assert L.mg_conv1d_wgrad_grouped_scratch_floats(256, 256, 1, 20) == 256 * 2 * (256 * 256 + 256)      # 1x1 wide tiles
+    assert L.mg_conv1d_wgrad_grouped_scratch_floats(128, 256, 1, 20) == 256 * 2 * (128 * 256 + 128)
+    assert L.mg_conv1d_wgrad_grouped_scratch_floats(512, 256, 3, 400) == 256 * (3200 // 256 + 2) * (3 * 128 * 128 + 128)
     assert L.mg_conv1d_wgrad_scratch_floats(256, 80, 1) == 128 * 256 * 80                     # 2 tiles, 256-workgroup target
     assert L.mg_conv1d_wgrad_scratch_floats(512, 128, 5) == 25 * 512 * 128 * 5                # k=5: split kernel, 20 tiles
     assert L.mg_conv1d_wgrad_grouped(None, 0, 0, None, 0, 0, None, 0, None, 2, 1, 8, 8, 8, 8, 1, 1, 0, 1.0, 0, None) == -1
