@@ -70,8 +70,14 @@ class FlatAdam(torch.optim.Adam):
     parameter `step`, `exp_avg`, `exp_avg_sq` -- here views of the flat moments), same `param_groups` (lr schedulers
     work unchanged).  Build it after the module is on its device; `.to()` afterwards would undo the aliasing."""
 
-    def __init__(self, bucket, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        super().__init__(bucket.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+    def __init__(self, bucket, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, param_order=None):
+        """param_order: the parameter list a stock optimizer would have been built over (e.g. `model.parameters()`,
+        utils/model.py:33) -- it fixes the index order of `state_dict()`, which is how checkpoints address the state;
+        the flat layout follows the bucket either way.  Must name exactly the bucket's parameters."""
+        order = list(param_order) if param_order is not None else list(bucket.params)
+        if {id(p) for p in order} != {id(p) for p in bucket.params} or len(order) != len(bucket.params):
+            raise ValueError("param_order must list exactly the parameters of the bucket")
+        super().__init__(order, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.bucket = bucket
         flat = bucket.flat
         if not flat.is_cuda:
@@ -112,6 +118,26 @@ class FlatAdam(torch.optim.Adam):
                       g["weight_decay"], int(self._steps.item()), scale)
         torch.autograd.graph.increment_version(self.bucket.params)    # derived caches (packed weights) key on it
         return self._norm if max_grad_norm is not None else None
+
+    def adopt(self, adam):
+        """Continue from a stock torch.optim.Adam over (a superset of) the same parameter objects -- e.g. the optG /
+        optD `get_model(..., train=True)` returns with a checkpoint's state loaded (utils/model.py:41-46): moments and
+        step count are copied by parameter identity, hyper-parameters from its first group."""
+        g0 = adam.param_groups[0]
+        for k in ("lr", "betas", "eps", "weight_decay"):
+            self.param_groups[0][k] = g0[k]
+        if "initial_lr" in g0:
+            self.param_groups[0]["initial_lr"] = g0["initial_lr"]
+        steps = 0.0
+        with torch.no_grad():
+            for p in self.bucket.params:
+                st = adam.state.get(p)
+                if st:
+                    self.state[p]["exp_avg"].copy_(st["exp_avg"])
+                    self.state[p]["exp_avg_sq"].copy_(st["exp_avg_sq"])
+                    steps = max(steps, float(st["step"]))
+        self._steps.fill_(steps)
+        return self
 
     def state_dict(self):
         """torch.optim.Adam's layout.  Every parameter gets its OWN `step` tensor: a stock Adam that loads this

@@ -20,7 +20,13 @@ from .optimizer import FlatAdam
 
 
 class HotPathTrainer:
-    def __init__(self, diffusion, discriminator, train_config, model_config, extra_g_params=()):
+    def __init__(self, diffusion, discriminator, train_config, model_config, extra_g_params=(), g_param_order=None,
+                 resume=None):
+        """extra_g_params: generator parameters outside `diffusion` that the G optimizer also steps (the injected
+        linguistic encoder, decoder ...).  g_param_order: the list the reference builds optG over (`model.parameters()`,
+        utils/model.py:33) so that `optG.state_dict()` indexes parameters the same way (default: diffusion's, then the
+        extras).  resume: (optG, optD, sdlG, sdlD) as returned by `get_model(..., train=True)` -- their restored state
+        (moments, step counts, learning rates, scheduler epochs) is taken over."""
         self.G, self.D = diffusion, discriminator
         oc = train_config["optimizer"]
         self.grad_clip = oc["grad_clip_thresh"]
@@ -37,13 +43,23 @@ class HotPathTrainer:
         # moments flat like the gradients, clip + step in two launches; on CPU (tests) torch's own
         if self.bucketG.flat.is_cuda:
             diffusion.denoise_fn.bind_grad_buffer(self.bucketG.flat, self.bucketG.offsets)
-            self.optG = FlatAdam(self.bucketG, lr=oc["init_lr_G"], betas=oc["betas"])
-            self.optD = FlatAdam(self.bucketD, lr=oc["init_lr_D"], betas=oc["betas"])
+            self.optG = FlatAdam(self.bucketG, lr=oc["init_lr_G"], betas=oc["betas"], param_order=g_param_order)
+            self.optD = FlatAdam(self.bucketD, lr=oc["init_lr_D"], betas=oc["betas"],
+                                 param_order=list(discriminator.parameters()))
         else:
-            self.optG = torch.optim.Adam(g_params, lr=oc["init_lr_G"], betas=oc["betas"])
+            self.optG = torch.optim.Adam(g_param_order or g_params, lr=oc["init_lr_G"], betas=oc["betas"])
             self.optD = torch.optim.Adam(discriminator.parameters(), lr=oc["init_lr_D"], betas=oc["betas"])
+        if resume is not None:
+            for mine, theirs in ((self.optG, resume[0]), (self.optD, resume[1])):
+                if isinstance(mine, FlatAdam):
+                    mine.adopt(theirs)
+                else:
+                    mine.load_state_dict(theirs.state_dict())
         self.sdlG = torch.optim.lr_scheduler.ExponentialLR(self.optG, gamma=oc["gamma"])    # stepped per EPOCH
         self.sdlD = torch.optim.lr_scheduler.ExponentialLR(self.optD, gamma=oc["gamma"])
+        if resume is not None:
+            self.sdlG.load_state_dict(resume[2].state_dict())
+            self.sdlD.load_state_dict(resume[3].state_dict())
         self.d_loss_fn, self.g_loss_fn = losses.get_adversarial_losses_fn(train_config["loss"]["adv_loss_mode"])
 
     # LSGAN and feature-matching sums as one launch each way (losses.weighted_means); False keeps one launch pair per

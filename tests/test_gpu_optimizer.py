@@ -72,6 +72,43 @@ def test_flat_adam_matches_torch_adam(mg, clip, wd):
     assert float(opt2.state[ours2[0]]["step"]) == 7
 
 
+def test_flat_adam_adopts_a_restored_stock_adam_and_keeps_its_index_order(mg):
+    """The resume path: get_model() hands back torch.optim.Adam objects with a checkpoint's state (utils/model.py:41-46);
+    the trainer's FlatAdam takes that over by parameter identity and, built with the same param_order, writes state
+    dicts that index parameters as the stock optimizer does."""
+    params = make_params(9, "cuda")
+    stock = torch.optim.Adam(params, lr=3e-4, betas=(0.5, 0.9))
+    g = torch.Generator().manual_seed(2)
+    for _ in range(2):
+        for p in params:
+            p.grad = torch.randn(p.shape, generator=g).cuda()
+        stock.step()
+    sched = torch.optim.lr_scheduler.ExponentialLR(stock, gamma=0.9)
+    sched.step()
+    twin = [torch.nn.Parameter(p.detach().clone()) for p in params]              # what the stock optimizer would do next
+    stock2 = torch.optim.Adam(twin, lr=1.0)
+    stock2.load_state_dict(stock.state_dict())
+    bucket = mg.GradBucket(params, order=[params[4], params[2]])
+    flat = mg.FlatAdam(bucket, lr=1.0, param_order=params).adopt(stock)
+    assert flat.param_groups[0]["lr"] == stock.param_groups[0]["lr"] and flat.param_groups[0]["betas"] == (0.5, 0.9)
+    sd, ref = flat.state_dict(), stock.state_dict()
+    assert sd["param_groups"][0]["params"] == ref["param_groups"][0]["params"]
+    for k in ref["state"]:
+        assert float(sd["state"][k]["step"]) == float(ref["state"][k]["step"]) == 2
+        assert torch.equal(sd["state"][k]["exp_avg"], ref["state"][k]["exp_avg"])           # same index -> same parameter
+        assert torch.equal(sd["state"][k]["exp_avg_sq"], ref["state"][k]["exp_avg_sq"])
+    grads = [torch.randn(p.shape, generator=g).cuda() for p in params]
+    for p, q, gr in zip(params, twin, grads):
+        p.grad, q.grad = gr.clone(), gr.clone()
+    bucket.gather()
+    flat.step()
+    stock2.step()
+    for p, q in zip(params, twin):
+        torch.testing.assert_close(p.detach(), q.detach(), rtol=2e-6, atol=1e-6)
+    with pytest.raises(ValueError):
+        mg.FlatAdam(bucket, lr=1.0, param_order=params[:-1])
+
+
 def test_grad_norm_tail_and_arg_checks(mg):
     import ctypes
     L = mg._lib.lib()

@@ -178,6 +178,60 @@ def test_trainer_fused_and_per_term_losses_agree(mg, manifest, tmp_path):
         assert_close(seen[True][1][name].cpu(), seen[False][1][name].cpu(), 2e-5, "bucket " + name)
 
 
+def test_checkpoint_resume_through_the_trainer(mg, manifest, tmp_path):
+    """utils/model.py:12-53 + train.py:252-267 around the HIP trainer: get_model() -> HotPathTrainer(resume=...) -> two
+    steps + an epoch -> save_checkpoint with the trainer's optimizers -> get_model(restore_step) hands back stock Adam
+    objects whose state a second trainer adopts; both trainers then take the same third step."""
+    import types
+    e = golden("elementwise")
+    stats = write_stats(tmp_path, e["spec_min"], e["spec_max"])
+    args, pre, mc, tr = hot_path_configs("naive", 4, stats_dir=stats)
+    tr = dict(tr)
+    tr["path"] = {"ckpt_path": str(tmp_path / "ckpt")}
+    tr["step"] = {"total_step_aux": 7}
+    tr["optimizer_fs2"] = {"betas": [0.9, 0.98], "eps": 1e-9, "weight_decay": 0.0, "warm_up_step": 4000,
+                           "anneal_steps": [300000], "anneal_rate": 0.3}
+    configs = (pre, mc, tr)
+    gen = torch.Generator().manual_seed(3)
+    B, L = 2, 48
+    mel = (torch.rand(B, L, 80, generator=gen) * 13.5 - 11.5).cuda()
+    cond = torch.randn(B, L, 256, generator=gen).cuda()
+    pad = torch.zeros(B, L, dtype=torch.bool).cuda()
+
+    def trainer_for(restore_step):
+        a = types.SimpleNamespace(model="naive", restore_step=restore_step)
+        model, D, f, g, d, sg, sd, epoch = mg.get_model(a, configs, "cuda", train=True)
+        t = mg.HotPathTrainer(model.diffusion, D, tr, mc, g_param_order=list(model.parameters()), resume=(g, d, sg, sd))
+        return model, D, f, t, epoch
+    model, D, f, t1, _ = trainer_for(0)
+    with torch.no_grad():   # the output projection starts at zero (model/modules.py:418): give the gradients something to do
+        model.diffusion.denoise_fn.output_projection.conv.weight.normal_(0, 0.05, generator=None)
+    for s_ in range(2):
+        torch.manual_seed(10 + s_)
+        t1.step(mel, cond, None, pad)
+    t1.end_epoch()
+    mg.save_checkpoint(tr, 2, 3, model, D, f, t1.optG, t1.optD, t1.sdlG, t1.sdlD)
+    m2, D2, f2, t2, epoch = trainer_for(2)
+    assert epoch == 3
+    assert t2.optG.param_groups[0]["lr"] == t1.optG.param_groups[0]["lr"] == pytest.approx(1e-4 * 0.999)
+    assert t2.sdlG.last_epoch == t1.sdlG.last_epoch == 1
+    for a_, b_ in ((t1.optG, t2.optG), (t1.optD, t2.optD)):
+        assert float(b_._steps) == float(a_._steps) == 2
+        assert torch.equal(a_.flat_m, b_.flat_m) and torch.equal(a_.flat_v, b_.flat_v) and torch.equal(a_.flat_p, b_.flat_p)
+    # a restarted process has no leaked D gradients from the previous G phase (they are not checkpointed, in the
+    # reference either): drop them on the running side so that both take the same step
+    for p in D.parameters():
+        p.grad = None
+    for tt in (t1, t2):
+        torch.manual_seed(99)
+        tt.step(mel, cond, None, pad)
+    # not bitwise: a few reductions on the path combine partial sums with atomics (mel L1, the small per-sample GEMMs)
+    for (k, p), q in zip(model.named_parameters(), m2.parameters()):
+        assert_close(p.detach().cpu(), q.detach().cpu(), 1e-5, k)
+    for (k, p), q in zip(D.named_parameters(), D2.parameters()):
+        assert_close(p.detach().cpu(), q.detach().cpu(), 1e-5, k)
+
+
 def test_batch_shard_gradients_average_to_the_full_batch(mg, manifest, tmp_path):
     """What the multi-GPU design rests on: with equal shard sizes and equal frame counts, the
     mean over ranks of the per-shard generator gradients equals the single-process gradient of the whole batch --
