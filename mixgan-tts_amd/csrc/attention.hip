@@ -28,8 +28,10 @@
 // KSPLIT: a 64-query workgroup whose wave pairs share the queries and split the keys of every tile (wave = 2 * query
 // group + key half), merged through LDS at the end.  Twice the workgroups for short sequences: B=16, L=1000, 2 heads is
 // 256 workgroups of 128 queries -- one per CU, one wave per SIMD, nothing to hide the staging behind.
-template <bool VEC, bool KSPLIT>
-__global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const float *__restrict__ qkv,
+// NWQ: query waves per workgroup (4: 128 queries; 8: 256 queries -- every staged key tile then serves twice the queries:
+// half the K/V re-reads from L2 and half the staging work per FLOP, for sequences long enough to still fill the chip).
+template <bool VEC, bool KSPLIT, int NWQ = 4>
+__global__ __launch_bounds__(NWQ * 64, 2) void attention_fwd_kernel(const float *__restrict__ qkv,
                                                                const uint8_t *__restrict__ key_pad,
                                                                float *__restrict__ out, int L, int n_head, float scale)
 {
@@ -40,7 +42,10 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const float *__re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, r = lane & 31;
     const int b = blockIdx.z, head = blockIdx.y;
-    const int q0 = KSPLIT ? blockIdx.x * 64 + (wave >> 1) * 32 : blockIdx.x * 128 + wave * 32;
+    static_assert(!KSPLIT || NWQ == 4, "the key-split form has 4 waves");
+    constexpr int KCH = AT_D * 64 / (NWQ * 64);   // K channels per staging thread: 32 (4 waves) or 16 (8)
+    constexpr int NVR = 2048 / (NWQ * 64);        // V float4s per staging thread: 8 or 4
+    const int q0 = KSPLIT ? blockIdx.x * 64 + (wave >> 1) * 32 : blockIdx.x * (NWQ * 32) + wave * 32;
     const int HD = n_head * AT_D;
     const float *Q = qkv + ((size_t)b * 3 * HD + head * AT_D) * L;
     const float *K = Q + (size_t)HD * L;
@@ -51,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const float *__re
     {
         const int q = min(q0 + r, L - 1);
 #pragma unroll
-        for (int s = 0; s < AT_D / 2; ++s) qf[s] = Q[(size_t)(2 * s + hh) * L + q] * scale;
+        for (int s = 0; s < AT_D / 2; ++s) qf[s] = Q[(size_t)(2 * s + hh) * L + q] * (scale * 1.44269504088896341f);
     }
     f32x16 O[4];
 #pragma unroll
@@ -63,18 +68,18 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const float *__re
     // staging roles.  K: thread <-> (key, 32 channels): 32 coalesced row reads, 8 ds_write_b128 into the key's row.
     //                 V: thread <-> (channel, 4 keys) x 8: one 16-byte read, one ds_write_b128.
     const int skey = tid & 63, sdq = tid >> 6;
-    float kreg[32];
-    f32x4 vreg[8];
+    float kreg[KCH];
+    f32x4 vreg[NVR];
     bool kmasked = false;
     auto load_tile = [&](int kt0) {
         const int key = kt0 + skey;
         const int kc = min(key, L - 1);
-        const float *kp = K + (size_t)(32 * sdq) * L + kc;
+        const float *kp = K + (size_t)(KCH * sdq) * L + kc;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) kreg[i] = kp[(size_t)i * L];
+        for (int i = 0; i < KCH; ++i) kreg[i] = kp[(size_t)i * L];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int d = (tid >> 4) + 16 * k, k4 = tid & 15;
+        for (int k = 0; k < NVR; ++k) {
+            const int d = (tid >> 4) + (NWQ * 4) * k, k4 = tid & 15;
             const int f0 = kt0 + 4 * k4;
             if (VEC) {
                 vreg[k] = *reinterpret_cast<const f32x4 *>(V + (size_t)d * L + min(f0, L - 4));
@@ -90,21 +95,21 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const float *__re
         if (tid < AT_KT) kmasked = key >= L || (key_pad && key_pad[(size_t)b * L + kc]);
         if (key >= L) {
 #pragma unroll
-            for (int i = 0; i < 32; ++i) kreg[i] = 0.f;
+            for (int i = 0; i < KCH; ++i) kreg[i] = 0.f;
         }
     };
     auto store_tile = [&]() {
-        float *kd = Kt + skey * AT_RSK + 32 * sdq;
+        float *kd = Kt + skey * AT_RSK + KCH * sdq;
 #pragma unroll
-        for (int sg = 0; sg < 4; ++sg) {
+        for (int sg = 0; sg < KCH / 8; ++sg) {
             const f32x4 even = {kreg[8 * sg], kreg[8 * sg + 2], kreg[8 * sg + 4], kreg[8 * sg + 6]};
             const f32x4 odd = {kreg[8 * sg + 1], kreg[8 * sg + 3], kreg[8 * sg + 5], kreg[8 * sg + 7]};
             *reinterpret_cast<f32x4 *>(kd + 8 * sg) = even;
             *reinterpret_cast<f32x4 *>(kd + 8 * sg + 4) = odd;
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            *reinterpret_cast<f32x4 *>(Vt + ((tid >> 4) + 16 * k) * AT_RSV + 4 * (tid & 15)) = vreg[k];
+        for (int k = 0; k < NVR; ++k)
+            *reinterpret_cast<f32x4 *>(Vt + ((tid >> 4) + (NWQ * 4) * k) * AT_RSV + 4 * (tid & 15)) = vreg[k];
         if (tid < AT_KT) {
             const unsigned long long bal = __ballot(kmasked);   // wave 0: lane j <-> key j of the tile
             if (tid == 0) {
@@ -133,25 +138,41 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const float *__re
                 for (int e = 0; e < 4; ++e) S = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], qf[4 * sg + e], S, 0, 0, 0);
             }
             // S[p] = score(key = kb*32 + 8(p>>2) + 4h + (p&3), query = r)
-            const unsigned mw = kmask[kb] >> (4 * hh);
-            float mx = AT_NEG;
+            // scores are in log2 units (Q carries scale * log2 e): the exponentials are bare v_exp_f32.  Blocks without a
+            // masked key -- all but the last tile of an unpadded utterance -- skip the per-element mask arithmetic, which
+            // is as many VALU cycles as the softmax itself.
+            const unsigned kw = __builtin_amdgcn_readfirstlane(kmask[kb]);
+            float mx = AT_NEG, ps = 0.f, m_new, corr;
+            if (kw == 0u) {
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const bool masked = (mw >> (8 * (p >> 2) + (p & 3))) & 1u;
-                const float v = masked ? AT_NEG : S[p];
-                S[p] = v;
-                mx = fmaxf(mx, v);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float corr = __expf(m_run - m_new);
-            float ps = 0.f;
+                for (int p = 0; p < 16; ++p) mx = fmaxf(mx, S[p]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                m_new = fmaxf(m_run, mx);
+                corr = __builtin_amdgcn_exp2f(m_run - m_new);
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const bool masked = (mw >> (8 * (p >> 2) + (p & 3))) & 1u;
-                const float e = masked ? 0.f : __expf(S[p] - m_new);
-                S[p] = e;
-                ps += e;
+                for (int p = 0; p < 16; ++p) {
+                    S[p] = __builtin_amdgcn_exp2f(S[p] - m_new);
+                    ps += S[p];
+                }
+            } else {
+                const unsigned mw = kw >> (4 * hh);
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    const bool masked = (mw >> (8 * (p >> 2) + (p & 3))) & 1u;
+                    const float v = masked ? AT_NEG : S[p];
+                    S[p] = v;
+                    mx = fmaxf(mx, v);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                m_new = fmaxf(m_run, mx);
+                corr = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    const bool masked = (mw >> (8 * (p >> 2) + (p & 3))) & 1u;
+                    const float e = masked ? 0.f : __builtin_amdgcn_exp2f(S[p] - m_new);
+                    S[p] = e;
+                    ps += e;
+                }
             }
             ps += __shfl_xor(ps, 32, 64);
             l_run = l_run * corr + ps;
@@ -194,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_kernel(const float *__re
         if (wave & 1) return;
         const float m1 = park[0], l1 = park[1];
         const float m = fmaxf(m_run, m1);
-        const float c0 = __expf(m_run - m), c1 = __expf(m1 - m);
+        const float c0 = __builtin_amdgcn_exp2f(m_run - m), c1 = __builtin_amdgcn_exp2f(m1 - m);   // log2 units
         l_run = l_run * c0 + l1 * c1;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -234,8 +255,8 @@ typedef _Float16 mg_half2 __attribute__((ext_vector_type(2)));
 
 // Round 2: as the fp32 kernel -- the next key tile's global loads fly behind the current tile's work, fragments are single
 // 16-byte LDS reads, the key mask is a ballot word, the accumulator rescale is skipped while the running maximum rests.
-template <bool VEC>
-__global__ __launch_bounds__(256, 2) void attention_fwd_f16_kernel(const float *__restrict__ qkv,
+template <bool VEC, int NWQ = 4>
+__global__ __launch_bounds__(NWQ * 64, 2) void attention_fwd_f16_kernel(const float *__restrict__ qkv,
                                                                    const uint8_t *__restrict__ key_pad,
                                                                    float *__restrict__ out, int L, int n_head,
                                                                    float scale)
@@ -247,7 +268,8 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_f16_kernel(const float *
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, r = lane & 31;
     const int b = blockIdx.z, head = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    constexpr int KCH = AT_D * 64 / (NWQ * 64), NVR = 2048 / (NWQ * 64);   // staging shares, as in the fp32 kernel
+    const int q0 = blockIdx.x * (NWQ * 32) + wave * 32;
     const int HD = n_head * AT_D;
     const float *Q = qkv + ((size_t)b * 3 * HD + head * AT_D) * L;
     const float *K = Q + (size_t)HD * L;
@@ -259,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_f16_kernel(const float *
 #pragma unroll
         for (int s = 0; s < AT_D / 16; ++s)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) qf[s][j] = (_Float16)(Q[(size_t)(16 * s + 8 * hh + j) * L + q] * scale);
+            for (int j = 0; j < 8; ++j) qf[s][j] = (_Float16)(Q[(size_t)(16 * s + 8 * hh + j) * L + q] * (scale * 1.44269504088896341f));
     }
     f32x16 O[4];
 #pragma unroll
@@ -269,18 +291,18 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_f16_kernel(const float *
     float m_run = AT_NEG, l_run = 0.f;
 
     const int skey = tid & 63, sdq = tid >> 6;
-    float kreg[32];
-    f32x4 vreg[8];
+    float kreg[KCH];
+    f32x4 vreg[NVR];
     bool kmasked = false;
     auto load_tile = [&](int kt0) {
         const int key = kt0 + skey;
         const int kc = min(key, L - 1);
-        const float *kp = K + (size_t)(32 * sdq) * L + kc;
+        const float *kp = K + (size_t)(KCH * sdq) * L + kc;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) kreg[i] = kp[(size_t)i * L];
+        for (int i = 0; i < KCH; ++i) kreg[i] = kp[(size_t)i * L];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int d = (tid >> 4) + 16 * k, k4 = tid & 15;
+        for (int k = 0; k < NVR; ++k) {
+            const int d = (tid >> 4) + (NWQ * 4) * k, k4 = tid & 15;
             const int f0 = kt0 + 4 * k4;
             if (VEC) {
                 vreg[k] = *reinterpret_cast<const f32x4 *>(V + (size_t)d * L + min(f0, L - 4));
@@ -296,21 +318,21 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_f16_kernel(const float *
         if (tid < AT_KT) kmasked = key >= L || (key_pad && key_pad[(size_t)b * L + kc]);
         if (key >= L) {
 #pragma unroll
-            for (int i = 0; i < 32; ++i) kreg[i] = 0.f;
+            for (int i = 0; i < KCH; ++i) kreg[i] = 0.f;
         }
     };
     auto store_tile = [&]() {
-        _Float16 *kd = Kt + skey * AH_KRS + 32 * sdq;
+        _Float16 *kd = Kt + skey * AH_KRS + KCH * sdq;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < KCH / 8; ++c) {
             mg_half8 hv;
 #pragma unroll
             for (int j = 0; j < 8; ++j) hv[j] = (_Float16)kreg[8 * c + j];
             *reinterpret_cast<mg_half8 *>(kd + 8 * c) = hv;
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int d = (tid >> 4) + 16 * k, k4 = tid & 15;
+        for (int k = 0; k < NVR; ++k) {
+            const int d = (tid >> 4) + (NWQ * 4) * k, k4 = tid & 15;
             // keys 4 k4 .. 4 k4 + 3: group of 16 = k4 >> 2, inside it quad (k4 & 3): h = quad & 1, hi = quad >> 1
             const int pos = 16 * (k4 >> 2) + 8 * (k4 & 1) + 4 * ((k4 >> 1) & 1);
             mg_half4 hv;
@@ -343,25 +365,41 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_f16_kernel(const float *
             for (int s = 0; s < AT_D / 16; ++s)
                 S = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const mg_half8 *>(Kp + 16 * s), qf[s], S, 0, 0, 0);
             // S[p] = score(key = kb*32 + 8(p>>2) + 4h + (p&3), query = r)
-            const unsigned mw = kmask[kb] >> (4 * hh);
-            float mx = AT_NEG;
+            // scores are in log2 units (Q carries scale * log2 e): the exponentials are bare v_exp_f32.  Blocks without a
+            // masked key -- all but the last tile of an unpadded utterance -- skip the per-element mask arithmetic, which
+            // is as many VALU cycles as the softmax itself.
+            const unsigned kw = __builtin_amdgcn_readfirstlane(kmask[kb]);
+            float mx = AT_NEG, ps = 0.f, m_new, corr;
+            if (kw == 0u) {
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const bool masked = (mw >> (8 * (p >> 2) + (p & 3))) & 1u;
-                const float v = masked ? AT_NEG : S[p];
-                S[p] = v;
-                mx = fmaxf(mx, v);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);
-            const float corr = __expf(m_run - m_new);
-            float ps = 0.f;
+                for (int p = 0; p < 16; ++p) mx = fmaxf(mx, S[p]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                m_new = fmaxf(m_run, mx);
+                corr = __builtin_amdgcn_exp2f(m_run - m_new);
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const bool masked = (mw >> (8 * (p >> 2) + (p & 3))) & 1u;
-                const float e = masked ? 0.f : __expf(S[p] - m_new);
-                S[p] = e;
-                ps += e;
+                for (int p = 0; p < 16; ++p) {
+                    S[p] = __builtin_amdgcn_exp2f(S[p] - m_new);
+                    ps += S[p];
+                }
+            } else {
+                const unsigned mw = kw >> (4 * hh);
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    const bool masked = (mw >> (8 * (p >> 2) + (p & 3))) & 1u;
+                    const float v = masked ? AT_NEG : S[p];
+                    S[p] = v;
+                    mx = fmaxf(mx, v);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                m_new = fmaxf(m_run, mx);
+                corr = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+                for (int p = 0; p < 16; ++p) {
+                    const bool masked = (mw >> (8 * (p >> 2) + (p & 3))) & 1u;
+                    const float e = masked ? 0.f : __builtin_amdgcn_exp2f(S[p] - m_new);
+                    S[p] = e;
+                    ps += e;
+                }
             }
             ps += __shfl_xor(ps, 32, 64);
             l_run = l_run * corr + ps;
@@ -399,15 +437,30 @@ __global__ __launch_bounds__(256, 2) void attention_fwd_f16_kernel(const float *
     }
 }
 
+// 256-query workgroups (8 waves) when they still number two per CU; MG_ATTENTION_WIDE=0/1 pins the choice (tests)
+static bool attention_wide(int L, int n_head, int B)
+{
+    const char *e = std::getenv("MG_ATTENTION_WIDE");
+    if (e) return e[0] == '1';
+    return (long)mg_cdiv(L, 256) * n_head * B >= 512;
+}
+
 extern "C" int mg_attention_fwd_f16(const float *qkv, const uint8_t *key_pad, float *out, int B, int L, int n_head,
                                     int d_head, float scale, void *stream)
 {
     if (!qkv || !out) return MG_ERR_ARG;
     if (B <= 0 || L <= 0 || n_head <= 0 || d_head != AT_D) return MG_ERR_SHAPE;
-    dim3 grid(mg_cdiv(L, 128), n_head, B);
     const bool vec = (L % 4 == 0) && (((uintptr_t)qkv & 15) == 0);
-    if (vec) hipLaunchKernelGGL(attention_fwd_f16_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, qkv, key_pad, out, L, n_head, scale);
-    else hipLaunchKernelGGL(attention_fwd_f16_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, qkv, key_pad, out, L, n_head, scale);
+    hipStream_t st = (hipStream_t)stream;
+    if (attention_wide(L, n_head, B)) {   // 256-query workgroups
+        dim3 grid(mg_cdiv(L, 256), n_head, B);
+        if (vec) hipLaunchKernelGGL((attention_fwd_f16_kernel<true, 8>), grid, dim3(512), 0, st, qkv, key_pad, out, L, n_head, scale);
+        else hipLaunchKernelGGL((attention_fwd_f16_kernel<false, 8>), grid, dim3(512), 0, st, qkv, key_pad, out, L, n_head, scale);
+    } else {
+        dim3 grid(mg_cdiv(L, 128), n_head, B);
+        if (vec) hipLaunchKernelGGL((attention_fwd_f16_kernel<true, 4>), grid, dim3(256), 0, st, qkv, key_pad, out, L, n_head, scale);
+        else hipLaunchKernelGGL((attention_fwd_f16_kernel<false, 4>), grid, dim3(256), 0, st, qkv, key_pad, out, L, n_head, scale);
+    }
     MG_LAUNCH_CHECK();
     return MG_OK;
 }
@@ -423,7 +476,11 @@ extern "C" int mg_attention_fwd(const float *qkv, const uint8_t *key_pad, float 
     const bool ksplit = ke ? ke[0] == '1' : (long)mg_cdiv(L, 128) * n_head * B < 512;
     dim3 grid(mg_cdiv(L, ksplit ? 64 : 128), n_head, B);
     hipStream_t st = (hipStream_t)stream;
-    if (ksplit) {
+    if (!ksplit && attention_wide(L, n_head, B)) {
+        dim3 wgrid(mg_cdiv(L, 256), n_head, B);
+        if (vec) hipLaunchKernelGGL((attention_fwd_kernel<true, false, 8>), wgrid, dim3(512), 0, st, qkv, key_pad, out, L, n_head, scale);
+        else hipLaunchKernelGGL((attention_fwd_kernel<false, false, 8>), wgrid, dim3(512), 0, st, qkv, key_pad, out, L, n_head, scale);
+    } else if (ksplit) {
         if (vec) hipLaunchKernelGGL((attention_fwd_kernel<true, true>), grid, dim3(256), 0, st, qkv, key_pad, out, L, n_head, scale);
         else hipLaunchKernelGGL((attention_fwd_kernel<false, true>), grid, dim3(256), 0, st, qkv, key_pad, out, L, n_head, scale);
     } else {

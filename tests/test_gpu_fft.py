@@ -50,10 +50,12 @@ def test_decoder_and_postnet_golden(mg, manifest):
     assert_close(pn(dev(g["x"])).cpu(), g["out"], TOL, "PostNet")
 
 
-@pytest.mark.parametrize("ksplit", ["0", "1"])   # 128-query workgroups / 64-query workgroups that split the keys
+# workgroup forms: 128 queries / 64 queries with the keys split between wave pairs / 256 queries (8 waves)
+@pytest.mark.parametrize("ksplit,wide", [("0", "0"), ("1", "0"), ("0", "1")])
 @pytest.mark.parametrize("B,L,lens", [(2, 300, [300, 171]), (3, 64, [64, 1, 33]), (1, 129, [129])])
-def test_attention_and_layernorm_vs_oracle(mg, manifest, monkeypatch, B, L, lens, ksplit):
+def test_attention_and_layernorm_vs_oracle(mg, manifest, monkeypatch, B, L, lens, ksplit, wide):
     monkeypatch.setenv("MG_ATTENTION_KSPLIT", ksplit)
+    monkeypatch.setenv("MG_ATTENTION_WIDE", wide)
     W, _ = seeded(manifest, "fftblock", 99)
     gen = torch.Generator().manual_seed(L)
     x = torch.randn(B, L, 256, generator=gen)
@@ -151,10 +153,12 @@ def test_attention_long_form_L4000(mg, manifest):
     assert_close(mg.ops.transpose_bml(y, True).cpu(), ref, 3e-5, "MHA L=4000")
 
 
+@pytest.mark.parametrize("wide", ["0", "1"])   # 128- / 256-query workgroups
 @pytest.mark.parametrize("B,L,lens", [(2, 300, [300, 171]), (3, 64, [64, 1, 33]), (1, 129, [129]), (1, 4000, [3777])])
-def test_attention_f16_mfma_path(mg, manifest, B, L, lens):
+def test_attention_f16_mfma_path(mg, manifest, monkeypatch, B, L, lens, wide):
     """BASELINE configs[4]: attention with fp16 MFMA operands (fp32 accumulate / statistics) against the exact
     fp32 kernel at the north_star tolerance, including the L = 4000 long-form length."""
+    monkeypatch.setenv("MG_ATTENTION_WIDE", wide)
     H, d = 2, 128
     gen = torch.Generator().manual_seed(L + B)
     qkv = torch.randn(B, 3 * H * d, L, generator=gen).cuda()
