@@ -38,14 +38,14 @@ __global__ __launch_bounds__(NWQ * 64, 2) void attention_fwd_kernel(const float 
     __shared__ __attribute__((aligned(16))) float Kt[AT_KT * AT_RSK];
     __shared__ __attribute__((aligned(16))) float Vt[AT_D * AT_RSV];
     __shared__ unsigned kmask[2];   // bit j of word kb: key kb*32 + j of the tile is masked
+    __shared__ float Pk[KSPLIT && NWQ == 8 ? 2 * 64 * 66 : 1];   // 8-wave key split: merge space of query groups 2, 3
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, r = lane & 31;
     const int b = blockIdx.z, head = blockIdx.y;
-    static_assert(!KSPLIT || NWQ == 4, "the key-split form has 4 waves");
     constexpr int KCH = AT_D * 64 / (NWQ * 64);   // K channels per staging thread: 32 (4 waves) or 16 (8)
     constexpr int NVR = 2048 / (NWQ * 64);        // V float4s per staging thread: 8 or 4
-    const int q0 = KSPLIT ? blockIdx.x * 64 + (wave >> 1) * 32 : blockIdx.x * (NWQ * 32) + wave * 32;
+    const int q0 = KSPLIT ? blockIdx.x * (NWQ * 16) + (wave >> 1) * 32 : blockIdx.x * (NWQ * 32) + wave * 32;
     const int HD = n_head * AT_D;
     const float *Q = qkv + ((size_t)b * 3 * HD + head * AT_D) * L;
     const float *K = Q + (size_t)HD * L;
@@ -202,7 +202,8 @@ __global__ __launch_bounds__(NWQ * 64, 2) void attention_fwd_kernel(const float 
         // merge the two key halves of a query group: the odd wave parks (m, l, O) in the K tile's storage
         // (2 query groups x 64 lanes x 66 floats = the tile's 8448 floats exactly)
         __syncthreads();   // the last tile is consumed
-        float *park = Kt + ((wave >> 1) * 64 + lane) * 66;
+        const int qg = wave >> 1;
+        float *park = (qg < 2 ? Kt + (qg * 64 + lane) * 66 : Pk + ((qg - 2) * 64 + lane) * 66);
         if (wave & 1) {
             park[0] = m_run;
             park[1] = l_run;
@@ -473,14 +474,19 @@ extern "C" int mg_attention_fwd(const float *qkv, const uint8_t *key_pad, float 
     const bool vec = (L % 4 == 0) && (((uintptr_t)qkv & 15) == 0);
     // fewer than two 128-query workgroups per CU: 64-query workgroups that split the keys between wave pairs
     const char *ke = std::getenv("MG_ATTENTION_KSPLIT");   // tests pin each form
-    const bool ksplit = ke ? ke[0] == '1' : (long)mg_cdiv(L, 128) * n_head * B < 512;
-    dim3 grid(mg_cdiv(L, ksplit ? 64 : 128), n_head, B);
+    // MG_ATTENTION_KSPLIT: 0 = never, 1 = 64-query workgroups (4 waves), 2 = 128-query workgroups (8 waves: four query
+    // groups x two key halves -- two waves per SIMD from ONE workgroup per CU, at the staging cost of the plain form)
+    const int ksplit = ke ? ke[0] - '0' : ((long)mg_cdiv(L, 128) * n_head * B < 512 ? 2 : 0);
+    dim3 grid(mg_cdiv(L, ksplit == 1 ? 64 : 128), n_head, B);
     hipStream_t st = (hipStream_t)stream;
     if (!ksplit && attention_wide(L, n_head, B)) {
         dim3 wgrid(mg_cdiv(L, 256), n_head, B);
         if (vec) hipLaunchKernelGGL((attention_fwd_kernel<true, false, 8>), wgrid, dim3(512), 0, st, qkv, key_pad, out, L, n_head, scale);
         else hipLaunchKernelGGL((attention_fwd_kernel<false, false, 8>), wgrid, dim3(512), 0, st, qkv, key_pad, out, L, n_head, scale);
-    } else if (ksplit) {
+    } else if (ksplit == 2) {
+        if (vec) hipLaunchKernelGGL((attention_fwd_kernel<true, true, 8>), grid, dim3(512), 0, st, qkv, key_pad, out, L, n_head, scale);
+        else hipLaunchKernelGGL((attention_fwd_kernel<false, true, 8>), grid, dim3(512), 0, st, qkv, key_pad, out, L, n_head, scale);
+    } else if (ksplit == 1) {
         if (vec) hipLaunchKernelGGL((attention_fwd_kernel<true, true>), grid, dim3(256), 0, st, qkv, key_pad, out, L, n_head, scale);
         else hipLaunchKernelGGL((attention_fwd_kernel<false, true>), grid, dim3(256), 0, st, qkv, key_pad, out, L, n_head, scale);
     } else {

@@ -50,8 +50,8 @@ def test_decoder_and_postnet_golden(mg, manifest):
     assert_close(pn(dev(g["x"])).cpu(), g["out"], TOL, "PostNet")
 
 
-# workgroup forms: 128 queries / 64 queries with the keys split between wave pairs / 256 queries (8 waves)
-@pytest.mark.parametrize("ksplit,wide", [("0", "0"), ("1", "0"), ("0", "1")])
+# workgroup forms: 128 queries / 64 and 128 queries with the keys split between wave pairs / 256 queries (8 waves)
+@pytest.mark.parametrize("ksplit,wide", [("0", "0"), ("1", "0"), ("2", "0"), ("0", "1")])
 @pytest.mark.parametrize("B,L,lens", [(2, 300, [300, 171]), (3, 64, [64, 1, 33]), (1, 129, [129])])
 def test_attention_and_layernorm_vs_oracle(mg, manifest, monkeypatch, B, L, lens, ksplit, wide):
     monkeypatch.setenv("MG_ATTENTION_KSPLIT", ksplit)
