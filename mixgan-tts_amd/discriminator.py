@@ -1,6 +1,8 @@
 """JCUDiscriminator (model/mixgantts.py:186-288): same constructor, state_dict keys,
 initialisation and forward contract as the reference; every convolution, the step MLP and the
 layout changes run in the HIP library (forward and backward, through mixgan_tts_amd.autograd)."""
+import os
+
 import torch
 from torch import nn
 
@@ -66,10 +68,33 @@ class JCUDiscriminator(nn.Module):
             cond_feats.append(x)
             uncond_feats.append(x)
         x_cond, x_uncond = x, x
+        # The two tails are independent and small (512 -> 128 -> 1 channels at L/4 frames: 128 workgroups per launch at
+        # B=16, L=1000, half the CUs): the unconditional one runs on a side stream next to the conditional one.  Autograd
+        # replays each backward on the stream its forward ran on, so the two backward chains overlap as well.
+        overlap = (self.branch_overlap and os.environ.get("MG_JCU_OVERLAP", "1") != "0" and x.is_cuda
+                   and not torch.cuda.is_current_stream_capturing())
+        if overlap:
+            main = torch.cuda.current_stream(dev)
+            if self._side is None or self._side.device != dev:
+                self._side = torch.cuda.Stream(device=dev)
+            side = self._side
+            side.wait_stream(main)
+            x.record_stream(side)
+            with torch.cuda.stream(side):
+                for layer in self.uncond_conv_block:
+                    x_uncond = self._lrelu_conv(layer, x_uncond)
+                    x_uncond.record_stream(main)          # consumed (losses, backward) on the main stream
+                    uncond_feats.append(x_uncond)
         for i, layer in enumerate(self.cond_conv_block):
             x_cond = self._lrelu_conv(layer, x_cond, step if i == 0 else None)    # (x + step[:, :, None]) fused
             cond_feats.append(x_cond)
-        for layer in self.uncond_conv_block:
-            x_uncond = self._lrelu_conv(layer, x_uncond)
-            uncond_feats.append(x_uncond)
+        if overlap:
+            main.wait_stream(side)
+        else:
+            for layer in self.uncond_conv_block:
+                x_uncond = self._lrelu_conv(layer, x_uncond)
+                uncond_feats.append(x_uncond)
         return cond_feats, uncond_feats
+
+    branch_overlap = True     # False: both tails on the caller's stream, one after the other
+    _side = None
