@@ -44,13 +44,25 @@ class ScheduledOptim:
         return self.last_lr
 
     # -- optimizer surface used by train.py
-    def step(self):
+    def step(self, **inner):
+        """inner: keyword arguments for the wrapped optimizer's step (FlatAdam's max_grad_norm)."""
         self.current_step += 1
         self.last_lr = self.lr_at(self.current_step)
         for group in self._optimizer.param_groups:
             group["lr"] = self.last_lr
-        self._optimizer.step()
+        self._optimizer.step(**inner)
         return self.last_lr
+
+    def use_flat(self, bucket):
+        """Swap the inner torch.optim.Adam for a FlatAdam over `bucket` (same hyper-parameters, state taken over): the
+        `optG_fs2._optimizer.state_dict()` that train.py:257 checkpoints keeps its layout and parameter order."""
+        old = self._optimizer
+        g = old.param_groups[0]
+        order = [p for p in g["params"] if any(p is q for q in bucket.params)]
+        flat = FlatAdam(bucket, lr=g["lr"], betas=g["betas"], eps=g["eps"], weight_decay=g["weight_decay"],
+                        param_order=order if len(order) == len(bucket.params) else None)
+        self._optimizer = flat.adopt(old)
+        return self
 
     def zero_grad(self):
         self._optimizer.zero_grad()

@@ -164,6 +164,8 @@ class AuxTrainer:
         self.opt = ScheduledOptim(holder, train_config, model_config, current_step)
         self.grad_clip = train_config["optimizer"]["grad_clip_thresh"]
         self.bucket = GradBucket(self.params)
+        if self.bucket.flat.is_cuda:      # clip + Adam as two launches on flat buffers (optimizer.FlatAdam)
+            self.opt.use_flat(self.bucket)
 
     def acoustic_losses(self, cond, mel_targets, mel_pad_mask):
         m = self.model
@@ -183,7 +185,10 @@ class AuxTrainer:
             loss = loss + extra_loss
         loss.backward()
         self.bucket.all_reduce_mean()
-        torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
-        lr = self.opt.step()
+        if isinstance(self.opt._optimizer, FlatAdam):
+            lr = self.opt.step(max_grad_norm=self.grad_clip)
+        else:
+            torch.nn.utils.clip_grad_norm_(self.params, self.grad_clip)
+            lr = self.opt.step()
         self.opt.zero_grad()
         return {"mel_loss": mel_loss.detach(), "postnet_loss": postnet_loss.detach(), "lr": lr}

@@ -274,8 +274,8 @@ def test_aux_trainer_step_vs_oracle(mg, manifest, tmp_path):
             assert (got - gref).abs().sum().item() <= 2 * TOL * scale, k
     # optimizer: the clipped-gradient ScheduledOptim update equals torch Adam on the oracle gradients
     before = {k: named[k].detach().clone() for k in ("mel_linear.weight", "decoder.layer_stack.0.slf_attn.fc.weight")}
-    torch.nn.utils.clip_grad_norm_(params, 1.0)
-    lr = trainer.opt.step()
+    trainer.bucket.gather()                         # what AuxTrainer.step does: flat gradients, then clip + Adam on them
+    lr = trainer.opt.step(max_grad_norm=1.0)
     assert lr == pytest.approx(256 ** -0.5 * 4000 ** -1.5)
     for k, b in before.items():
         assert not torch.equal(b, named[k].detach())
