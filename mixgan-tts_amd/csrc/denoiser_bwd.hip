@@ -1,7 +1,8 @@
 // Backward of Denoiser.forward (model/modules.py:420-446; what torch.autograd derives for the
 // reference) on gfx950.  Every contraction is an fp32-MFMA GEMM:
 //   data gradients  = the forward conv kernel on transposed, tap-flipped packs (MG_PACK_DGRAD);
-//   weight gradients = wgrad_mfma_kernel (frames are the reduction axis);
+//   weight gradients = frames are the reduction axis: wgrad_stream_kernel for the residual stack (all taps from one
+//                      staged tile pair, bias row sums folded in), wgrad_mfma_kernel for the small projections;
 // gate / ReLU / residual derivatives are fused into the data-gradient epilogues.  The 20
 // conditioner projections share their input, so their data gradient (K = 20*256) and their weight
 // gradient (M = 20*256) run as ONE GEMM each over the stacked per-layer dh.

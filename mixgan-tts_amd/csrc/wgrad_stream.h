@@ -10,10 +10,14 @@
 // Here one 8-wave workgroup per CU walks a contiguous run of (tile, frame-chunk) UNITS -- every workgroup gets the
 // same number of units, whatever the tile count -- with all taps of a tile accumulated from ONE staged pair of
 // tiles (the X tile holds the aligned window that covers the three shifts; a tap is an address offset at read
-// time).  Tiles are double-buffered in LDS: the global loads of unit u+1 are issued before the MFMAs of unit u and
-// written to the other buffer after them, one barrier per unit.  When the run crosses into the next tile the
-// accumulators are flushed to a partial tile; the finalize kernel adds the (at most `maxseg` per workgroup) partials
-// of a tile in workgroup order -- a fixed summation order, like the split kernel -- and transposes to [Co][Ci][K].
+// time).  Tiles are double-buffered in LDS with one barrier per unit; the staging of unit u+1 is spread over the
+// k-steps of unit u (one global load per k-step at the front of the loop, one element to the other buffer per k-step in
+// its second half).  When the run crosses into the next tile the accumulators are flushed to a partial tile; the
+// finalize kernel adds the (at most `maxseg` per workgroup) partials of a tile in workgroup order -- a fixed summation
+// order, like the split kernel -- and transposes to [Co][Ci][K].  The row sums of dY (bias gradients) are collected
+// from the staging registers on the way (rs_part).  Measured: tools/ubench/wgrad_stream_bench.hip,
+// profiles/r02_e_wgrad_stream_ubench.txt (0.71 of the nominal fp32 MFMA peak on real data -- the clock, not the
+// schedule, is what gives: the same cycle count runs 15 % faster on all-zero operands).
 #pragma once
 #include "common.h"
 
