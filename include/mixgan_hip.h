@@ -224,6 +224,17 @@ int mg_denoiser_psample(const mg_denoiser_dims *d, const float *packed, const fl
                         const float *logvar, int n_steps, const float *noise, unsigned long long seed, int clip,
                         float *x_prev, float *x0_out, float *workspace, size_t workspace_floats, int B, int L, int mode,
                         void *stream);
+/* Both generator forwards of a GAN training step (train.py:133 and :153 -- same weights, different t / noise) as ONE
+ * launch of 64-frame tiles: problem A (x_tA, tA -> outA; nothing kept) is the D phase's no-grad forward, problem B
+ * (x_tB, tB -> outB) the G phase's: its layer activations land in wsB exactly as mg_denoiser_fwd(MG_FWD_SAVE) leaves
+ * them, so mg_denoiser_bwd runs on (x_tB, tB, wsB) unchanged.  Bh utterances per problem over the same cond [Bh, H, L]
+ * and spk.  wsA: mg_denoiser_workspace_floats(dims, 2 * Bh, L, 0) floats (zero before its first use, like every
+ * forward workspace); wsB: mg_denoiser_workspace_floats(dims, Bh, L, 1).  packed: with the backward packs or without.
+ * MG_ERR_SHAPE when the single-launch kernel does not take the shape -- run the two forwards separately then. */
+int mg_denoiser_fwd_pair(const mg_denoiser_dims *dims, const float *packed, const float *x_tA, const int64_t *tA,
+                         const float *x_tB, const int64_t *tB, const float *cond, const float *spk, float *outA,
+                         float *outB, float *wsA, size_t wsA_floats, float *wsB, size_t wsB_floats, int Bh, int L,
+                         void *stream);
 /* Copies the single-launch forward's counter words {ticket, error, launches, workgroups done} of a (B, L, no-save)
  * workspace to host_out4 and synchronises the stream: error != 0 means a neighbour hand-off timed out (the launch
  * drained instead of hanging; its output is invalid). */

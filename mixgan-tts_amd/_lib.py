@@ -23,7 +23,7 @@ EXPORTS = (
     "mg_loss_sum", "mg_loss_grad", "mg_mel_l1_fwd", "mg_mel_l1_bwd", "mg_attention_fwd", "mg_attention_fwd_f16", "mg_layernorm_cm_fwd",
     "mg_length_regulate_fwd", "mg_length_regulate_bwd", "mg_word_pool_fwd", "mg_word_pool_bwd", "mg_mapping_mask",
     "mg_rel_coef", "mg_resblock_fwd", "mg_gate_bwd", "mg_mish_fwd", "mg_mish_bwd", "mg_step_embed",
-    "mg_denoiser_psample", "mg_denoiser_persist_status",
+    "mg_denoiser_psample", "mg_denoiser_persist_status", "mg_denoiser_fwd_pair",
     "mg_grad_norm_scratch_floats", "mg_grad_norm", "mg_adam_flat",
     "mg_multi_loss_scratch_floats", "mg_multi_loss_fwd", "mg_multi_loss_bwd",
 )
@@ -118,6 +118,7 @@ def _declare(L):
         "mg_denoiser_bwd": (i, [dp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, i, i, vp]),
         "mg_denoiser_workspace_floats": (sz, [dp, i, i, i]),
         "mg_denoiser_fwd": (i, [dp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, vp]),
+        "mg_denoiser_fwd_pair": (i, [dp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, sz, i, i, vp]),
         "mg_transpose_bml_strided": (i, [vp] * 5 + [i, i, i, i, i, ctypes.c_long, vp]),
         "mg_act_bwd": (i, [vp, vp, vp, i, sz, vp]),
         "mg_upsample_zero": (i, [vp, vp, i, i, i, i, vp]),

@@ -58,11 +58,16 @@ class DenoiserFn(torch.autograd.Function):
     of the module at any shape, or a cache eviction, cannot take it away); backward = mg_denoiser_bwd."""
 
     @staticmethod
-    def forward(ctx, module, x, t, cond, spk, *params):
+    def forward(ctx, module, x, t, cond, spk, pre, *params):
+        """pre: None, or (out, ws) of a forward that already ran on exactly these inputs (Denoiser.run_pair): the node
+        then only adopts its output and saved activations."""
         _require_cuda(x, cond)
-        out = module.run(x, t, cond, spk, save=True)
+        if pre is None:
+            out = module.run(x, t, cond, spk, save=True)
+            ctx.ws = module.last_ws
+        else:
+            out, ctx.ws = pre
         ctx.module = module
-        ctx.ws = module.last_ws
         ctx.gen = ctx.ws._mg_gen
         ctx.save_for_backward(x, t, cond, spk if spk is not None else x.new_empty(0))
         ctx.has_spk = spk is not None
@@ -74,13 +79,13 @@ class DenoiserFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         d_x, d_cond, d_spk, pg = ctx.module.run_backward(g.contiguous(), x, t, cond, spk if ctx.has_spk else None,
                                                          ctx.ws, ctx.gen, need[1], need[3], need[4])
-        return (None, d_x, None, d_cond, d_spk) + tuple(pg)
+        return (None, d_x, None, d_cond, d_spk, None) + tuple(pg)
 
 
-def denoise_and_posterior(diff, x_t, t, cond_t, spk, post_noise, keep, clip, coarse_mel):
+def denoise_and_posterior(diff, x_t, t, cond_t, spk, post_noise, keep, clip, coarse_mel, pre=None):
     """Training branch of GaussianDiffusion.forward with autograd (model/diffusion.py:210-220)."""
     den = diff.denoise_fn
-    x0 = DenoiserFn.apply(den, x_t, t, cond_t, spk, *[p for p in den._weight_table() if p is not None])
+    x0 = DenoiserFn.apply(den, x_t, t, cond_t, spk, pre, *[p for p in den._weight_table() if p is not None])
     buf = diff._buf()
     if coarse_mel is None:
         x0c, xpp = _PosteriorFn.apply(x0, x_t, t, post_noise, keep, buf["posterior_mean_coef1"],

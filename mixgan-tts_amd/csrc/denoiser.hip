@@ -476,6 +476,26 @@ static std::atomic<unsigned> g_persist_epoch{0};
 static unsigned long long *g_persist_dbg = nullptr;
 extern "C" void mg_debug_persist_stamps(unsigned long long *device_buffer) { g_persist_dbg = device_buffer; }
 
+// step embedding -> MLP -> per-layer projections (model/modules.py:433-434, blocks.py:1159): fills ws.emb / h1pre / h1 / s
+// (kept for the backward in a save workspace) and the per-layer vectors dvec [NL][B][C] (hvec: + speaker projection)
+static int den_step_vectors(const mg_denoiser_dims *d, const DenLayout &o, const float *packed, const int64_t *t,
+                            const float *spk, float *ws, const DenWs &w, int B, hipStream_t st)
+{
+    const int C = d->channels, H = d->cond_channels, NL = d->n_layers;
+    const float *lay0 = packed + o.layers;
+    hipLaunchKernelGGL(step_embed_kernel, dim3(mg_cdiv(B * (C / 2), 256)), dim3(256), 0, st, t, packed + o.freq,
+                       ws + w.emb, B, C);
+    MG_LAUNCH_CHECK();
+    MG_TRY(small_linear(packed + o.mlp0, 0, ws + w.emb, ws + w.h1, 0, nullptr, 0, ws + w.h1pre, B, 4 * C, C, 1, 1, st));
+    MG_TRY(small_linear(packed + o.mlp2, 0, ws + w.h1, ws + w.s, 0, nullptr, 0, nullptr, B, C, 4 * C, 1, 0, st));
+    MG_TRY(small_linear(lay0 + o.l_wd, (long)o.layer_stride, ws + w.s, ws + w.dvec, (long)B * C, nullptr, 0, nullptr, B,
+                        C, C, NL, 0, st));
+    if (d->multi_speaker)
+        MG_TRY(small_linear(lay0 + o.l_wp, (long)o.layer_stride, spk, ws + w.hvec, (long)B * C, ws + w.dvec,
+                            (long)B * C, nullptr, B, C, H, NL, 0, st));
+    return MG_OK;
+}
+
 static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, const float *x_t, const int64_t *t,
                             const float *cond, const float *spk, float *out, float *ws, size_t ws_floats, int B,
                             int L, int mode, const PostSample *post, void *stream);
@@ -567,17 +587,7 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
     const DenLayout o = den_layout(d, (split ? MG_DEN_SPLIT : 0) | (has_p16 ? MG_DEN_P16 : 0));
     const float *lay0 = packed + o.layers;
 
-    // step embedding -> MLP -> per-layer projections (model/modules.py:433-434, blocks.py:1159)
-    hipLaunchKernelGGL(step_embed_kernel, dim3(mg_cdiv(B * (C / 2), 256)), dim3(256), 0, st, t, packed + o.freq,
-                       ws + w.emb, B, C);
-    MG_LAUNCH_CHECK();
-    MG_TRY(small_linear(packed + o.mlp0, 0, ws + w.emb, ws + w.h1, 0, nullptr, 0, ws + w.h1pre, B, 4 * C, C, 1, 1, st));
-    MG_TRY(small_linear(packed + o.mlp2, 0, ws + w.h1, ws + w.s, 0, nullptr, 0, nullptr, B, C, 4 * C, 1, 0, st));
-    MG_TRY(small_linear(lay0 + o.l_wd, (long)o.layer_stride, ws + w.s, ws + w.dvec, (long)B * C, nullptr, 0, nullptr, B,
-                        C, C, NL, 0, st));
-    if (d->multi_speaker)
-        MG_TRY(small_linear(lay0 + o.l_wp, (long)o.layer_stride, spk, ws + w.hvec, (long)B * C, ws + w.dvec,
-                            (long)B * C, nullptr, B, C, H, NL, 0, st));
+    MG_TRY(den_step_vectors(d, o, packed, t, spk, ws, w, B, st));
 
     static const bool force_generic = std::getenv("MG_DENOISER_GENERIC") != nullptr;
     const bool fused = !force_generic && C == RB_C && H == RB_C;
@@ -610,6 +620,9 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
     const int chain_cap = (nt == 64 || wide32) ? 64 : 128;   // a quarter of the 256 / 512 slots
     if (fused && !no_persist && !split && M <= 96 && NL >= 3 && tiles_per_b <= chain_cap) {
         PersistArgs a;
+        a.b_split = 0;
+        a.x_t2 = a.hvec2 = a.dvec2 = nullptr;
+        a.out2 = nullptr;
         a.x_t = x_t;
         a.cond = cond;
         a.in_w = packed + o.in_w;
@@ -831,4 +844,91 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
         MG_TRY(conv_launch<EpiBiasAct>(s, ws + w.y, nullptr, packed + o.out_w, ep, st));
     }
     return post ? psample_tail(*post, out, x_t, t, final_out, reinterpret_cast<unsigned *>(ws + w.sync), B, M, L, st) : MG_OK;
+}
+
+// Both generator forwards of a GAN training step (train.py:133 and :153: same weights, different t / noise) as ONE
+// launch: problem A = the D phase's no-grad forward, problem B = the G phase's saving forward, Bh utterances each over
+// the same conditioner.  wsA: a workspace for (2 Bh, L, no save) -- tickets, halo granules, A's step vectors; wsB: one for
+// (Bh, L, save) -- exactly what mg_denoiser_fwd(..., MG_FWD_SAVE) would have filled, so mg_denoiser_bwd consumes it
+// unchanged.  64-frame tiles: 2 Bh ceil(L/64) workgroups.  Returns MG_ERR_SHAPE when the single-launch kernel does
+// not take the shape (the caller then runs the two forwards separately).
+extern "C" int mg_denoiser_fwd_pair(const mg_denoiser_dims *d, const float *packed, const float *x_tA, const int64_t *tA,
+                                    const float *x_tB, const int64_t *tB, const float *cond, const float *spk, float *outA,
+                                    float *outB, float *wsA, size_t wsA_floats, float *wsB, size_t wsB_floats, int Bh, int L,
+                                    void *stream)
+{
+    MG_TRY(den_check(d));
+    if (!packed || !x_tA || !tA || !x_tB || !tB || !cond || !outA || !outB || !wsA || !wsB) return MG_ERR_ARG;
+    if (d->multi_speaker && !spk) return MG_ERR_ARG;
+    if (Bh <= 0 || L <= 0) return MG_ERR_SHAPE;
+    const int C = d->channels, H = d->cond_channels, M = d->mel_bins, NL = d->n_layers;
+    const int tiles_per_b = mg_cdiv(L, 64);
+    const char *pe = std::getenv("MG_DENOISER_PERSIST");
+    if ((pe && pe[0] == '0') || C != RB_C || H != RB_C || M > 96 || NL < 3 || tiles_per_b > 64) return MG_ERR_SHAPE;
+    const DenWs wA = den_ws(d, 2 * Bh, L, 0), wB = den_ws(d, Bh, L, 1);
+    if (wsA_floats < wA.total || wsB_floats < wB.total) return MG_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const DenLayout o = den_layout(d, 0);
+    MG_TRY(den_step_vectors(d, o, packed, tA, spk, wsA, wA, Bh, st));
+    MG_TRY(den_step_vectors(d, o, packed, tB, spk, wsB, wB, Bh, st));
+    PersistArgs a;
+    a.x_t = x_tA;
+    a.x_t2 = x_tB;
+    a.out = outA;
+    a.out2 = outB;
+    a.hvec = wsA + wA.hvec;
+    a.dvec = wsA + wA.dvec;
+    a.hvec2 = wsB + wB.hvec;
+    a.dvec2 = wsB + wB.dvec;
+    a.b_split = Bh;
+    a.cond = cond;
+    a.in_w = packed + o.in_w;
+    a.in_b = packed + o.in_b;
+    a.layers = packed + o.layers;
+    a.layer_stride = o.layer_stride;
+    a.l_wc = o.l_wc;
+    a.l_w3 = o.l_w3;
+    a.l_wo = o.l_wo;
+    a.l_bc = o.l_bc;
+    a.l_b3 = o.l_b3;
+    a.l_bo = o.l_bo;
+    a.skip_w = packed + o.skip_w;
+    a.skip_b = packed + o.skip_b;
+    a.out_w = packed + o.out_w;
+    a.out_b = packed + o.out_b;
+    a.p16layers = nullptr;
+    a.p16layer_stride = 0;
+    a.p_wc = a.p_w3 = a.p_wo = 0;
+    a.t = nullptr;
+    a.coef1 = a.coef2 = a.logvar = a.noise = nullptr;
+    a.seed = 0ull;
+    a.x0_out = nullptr;
+    a.gran = reinterpret_cast<dp_u64 *>(wsA + wA.gran);
+    a.sync = reinterpret_cast<unsigned *>(wsA + wA.sync);
+    a.epoch_base = g_persist_epoch.fetch_add((unsigned)NL + 1u);
+    a.B = 2 * Bh;
+    a.L = L;
+    a.M = M;
+    a.NL = NL;
+    a.tiles_per_b = tiles_per_b;
+    a.post = 0;
+    a.clip = 0;
+    a.n_steps = 1;
+    a.rsNL = 1.0f / sqrtf((float)NL);
+    a.dbg = nullptr;
+    a.x0_save = wsB + wB.x0;
+    a.y_save = wsB + wB.y;
+    a.skip_save = wsB + wB.skip;
+    a.h_save = wsB + wB.h;
+    a.g_save = wsB + wB.g;
+    a.sig_save = wsB + wB.sig;
+    a.tnh_save = wsB + wB.tnh;
+    a.act_stride = wB.act_stride;
+    a.flags = 0;
+    const bool vec4 = (L % 4 == 0) && (((uintptr_t)cond & 15) == 0);
+    dim3 grid((unsigned)(tiles_per_b * 2 * Bh));
+    if (vec4) hipLaunchKernelGGL((denoiser_persist_kernel<64, true, false, true>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((denoiser_persist_kernel<64, false, false, true>), grid, dim3(512), 0, st, a);
+    MG_LAUNCH_CHECK();
+    return MG_OK;
 }

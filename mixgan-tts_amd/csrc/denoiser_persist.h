@@ -65,6 +65,12 @@ struct PersistArgs {
     int B, L, M, NL, tiles_per_b, post, clip, n_steps;
     int flags;                            // DP_F_*
     float rsNL;
+    // Two problems in one grid (mg_denoiser_fwd_pair; b_split > 0): utterances [0, b_split) are problem 1 (x_t, out,
+    // hvec, dvec; nothing saved), [b_split, B) problem 2 (x_t2, out2, hvec2, dvec2; the SAVE stores, indexed from 0).
+    // Same weights, same conditioner rows (utterance b - b_split of problem 2 uses cond row b - b_split).  post == 0.
+    int b_split;
+    const float *x_t2, *hvec2, *dvec2;
+    float *out2;
 };
 
 // (chunk, tap) iteration orders of the k loops.  A "chunk" is 32 reduction channels, a k-group 8 of them.
@@ -241,7 +247,13 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
     }
     __syncthreads();
     const int tile = min((int)s_tile, n_tiles - 1);
-    const int b = tile / a.tiles_per_b, jt = tile - b * a.tiles_per_b;
+    const int bg = tile / a.tiles_per_b, jt = tile - bg * a.tiles_per_b;   // bg: utterance in the grid
+    const bool second = a.b_split > 0 && bg >= a.b_split;                   // wave-uniform (workgroup-uniform)
+    const int b = second ? bg - a.b_split : bg;                             // utterance inside its problem
+    const int Bp = a.b_split > 0 ? (second ? a.B - a.b_split : a.b_split) : a.B;
+    const bool do_save = SAVE && (a.b_split == 0 || second);
+    const float *const x_in = second ? a.x_t2 : a.x_t;
+    float *const x_out = second ? a.out2 : a.out;
     const int l0 = jt * NT;
     const bool has_left = jt > 0, has_right = jt + 1 < a.tiles_per_b;
     int stamp_row = 0;
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
                 condT[dp_at<NC>(row, cc)] = f < L ? v : 0.f;
             }
         }
-        const float *xb = a.x_t + (size_t)b * a.M * L;
+        const float *xb = x_in + (size_t)b * a.M * L;
 #pragma unroll
         for (int k = 0; k < 96 * NT / NTHR; ++k) {   // 96 rows (M = 80 padded) x NT frames -> hT channels 0..95, col c <-> frame l0+c
             const int idx = tid + k * NTHR;
@@ -331,7 +343,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
     };
 #pragma unroll
     for (int j = 0; j < NNB; ++j) fvalid[j] = l0 + 32 * j + c32 < L;
-    if (SAVE) {
+    if (SAVE && do_save) {
 #pragma unroll
         for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -342,8 +354,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
 
     for (int l = 0; l < a.NL; ++l) {
         const float *lp = a.layers + (size_t)l * a.layer_stride;
-        const float *hv = a.hvec + ((size_t)l * a.B + b) * RB_C;
-        const float *dv = a.dvec + ((size_t)l * a.B + b) * RB_C;
+        const float *hv = (second ? a.hvec2 : a.hvec) + ((size_t)l * Bp + b) * RB_C;
+        const float *dv = (second ? a.dvec2 : a.dvec) + ((size_t)l * Bp + b) * RB_C;
         const unsigned epoch = a.epoch_base + (unsigned)l + 1u;
         const int par = l & 1;
         stamp_row = l + 1;
@@ -389,7 +401,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
             {
                 dp_store_block<NH>(hT, rbase + 32 * i, 1 + 32 * j + c32, hh,   // zero padding of the conv applies to h
                                    [&](int r) { return fvalid[j] ? acc1[i][j][r] : 0.f; });
-                if (SAVE) save_block(a.h_save + (size_t)l * a.act_stride, rbase + 32 * i, j, [&](int r) { return acc1[i][j][r]; });
+                if (SAVE && do_save) save_block(a.h_save + (size_t)l * a.act_stride, rbase + 32 * i, j, [&](int r) { return acc1[i][j][r]; });
             }
         __syncthreads();   // interior columns of hT complete
         DP_STAMP(3);
@@ -470,7 +482,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
 #pragma unroll
             for (int j = 0; j < NNB; ++j)
             {
-                if (SAVE) {   // the backward's gate derivative needs sigmoid and tanh themselves
+                if (SAVE && do_save) {   // the backward's gate derivative needs sigmoid and tanh themselves
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         acc2[p][0][j][r] = mg_sigmoid(acc2[p][0][j][r]);
@@ -531,7 +543,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
         for (int j = 0; j < NNB; ++j)
             {
                 dp_store_block<NH>(hT, rbase + 32 * i, 32 * j + c32, hh, [&](int r) { return st[MB + i][j][r] * a.rsNL; });
-                if (SAVE) save_block(a.skip_save, rbase + 32 * i, j, [&](int r) { return st[MB + i][j][r]; });
+                if (SAVE && do_save) save_block(a.skip_save, rbase + 32 * i, j, [&](int r) { return st[MB + i][j][r]; });
             }
     __syncthreads();
     {
@@ -553,7 +565,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
             for (int j = 0; j < NNB; ++j)
             {
                 dp_store_block<NC>(condT, rbase + 32 * i, 32 * j + c32, hh, [&](int r) { return fmaxf(acc[i][j][r], 0.f); });
-                if (SAVE) save_block(a.y_save, rbase + 32 * i, j, [&](int r) { return fmaxf(acc[i][j][r], 0.f); });
+                if (SAVE && do_save) save_block(a.y_save, rbase + 32 * i, j, [&](int r) { return fmaxf(acc[i][j][r], 0.f); });
             }
     }
     __syncthreads();
@@ -574,7 +586,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = 32 * mb + 8 * (r >> 2) + 4 * hh + (r & 3);
-                if (row < a.M && f < L) a.out[bo + (size_t)row * L + f] = o[0][0][r];
+                if (row < a.M && f < L) x_out[bo + (size_t)row * L + f] = o[0][0][r];
             }
         } else {
             // p_sample tail (model/diffusion.py:113-129): clamp, posterior mean, + sigma * noise unless t == 0

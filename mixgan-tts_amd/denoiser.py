@@ -142,6 +142,30 @@ class Denoiser(nn.Module):
                                          ws.numel(), B, L, mode, stream_ptr()))
         return out
 
+    def run_pair(self, x_a, t_a, x_b, t_b, cond, spk):
+        """Two forwards over the same weights, conditioner and speakers in ONE launch (mg_denoiser_fwd_pair): problem a
+        without saves (the GAN step's D-phase forward), problem b with the activations kept like run(save=True) (its
+        G-phase forward; the workspace is left in `self.last_ws` / returned).  -> (out_a, out_b, ws_b), or None when the
+        single-launch kernel does not take the shape (run them separately then)."""
+        Bh, M, L = x_a.shape
+        packed = self.packed_weights(with_backward=True)
+        dev = x_a.device
+        ws_a = self._workspace(2 * Bh, L, False, dev)
+        ws_b = self._workspace(Bh, L, True, dev)
+        out_a, out_b = torch.empty_like(x_a), torch.empty_like(x_b)
+        rc = _lib.lib().mg_denoiser_fwd_pair(ctypes.byref(self._dims), fptr(packed), fptr(x_a), iptr(t_a, torch.int64),
+                                             fptr(x_b), iptr(t_b, torch.int64), fptr(cond),
+                                             fptr(spk, not self.multi_speaker), fptr(out_a), fptr(out_b), fptr(ws_a),
+                                             ws_a.numel(), fptr(ws_b), ws_b.numel(), Bh, L, stream_ptr())
+        if rc == -2:        # MG_ERR_SHAPE: not a shape of the single-launch kernel
+            return None
+        check(rc)
+        self._save_gen += 1
+        ws_b._mg_busy = True
+        ws_b._mg_gen = self._save_gen
+        self.last_ws = ws_b
+        return out_a, out_b, ws_b
+
     def p_sample(self, x_t, t, cond, spk, coef1, coef2, logvar, noise=None, clip=True, out=None, x0_out=None,
                  packed=None, ws=None):
         """One reverse step (model/diffusion.py:121-129) as one library call: x_0 = forward(x_t); clamp; posterior mean
@@ -188,7 +212,7 @@ class Denoiser(nn.Module):
             or any(p.requires_grad for p in self.parameters()))
         if needs_grad:
             from .autograd import DenoiserFn
-            return DenoiserFn.apply(self, x, t, cond, spk, *[p for p in self._weight_table() if p is not None])[:, None]
+            return DenoiserFn.apply(self, x, t, cond, spk, None, *[p for p in self._weight_table() if p is not None])[:, None]
         return self.run(x, t, cond, spk)[:, None]
 
     # ------------------------------------------------------------------ backward (autograd.DenoiserFn)

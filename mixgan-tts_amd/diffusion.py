@@ -217,6 +217,11 @@ class GaussianDiffusion(nn.Module):
             trace.append(ops.transpose_bml(self._bml(x), True))
         return trace
 
+    # HotPathTrainer sets this around its D-phase forward: the next (grad-enabled) forward on the same inputs is launched
+    # together with it (Denoiser.run_pair).  Off by default: it draws that second forward's randomness early.
+    pair_forward = False
+    _pair_stash = None
+
     def forward(self, mel, cond, spk_emb, mel_mask, coarse_mel=None, clip_denoised=True):
         """model/diffusion.py:187-226.  mel [B,L,M]|None, cond [B,L,H], mel_mask bool [B,L] True = pad."""
         B = cond.shape[0]
@@ -247,19 +252,54 @@ class GaussianDiffusion(nn.Module):
             x_0_pred = self.sampling(noise=noise, keep_trace=False, use_graph=self.use_graph, _final_keep=keep)[-1]
             return x_0_pred, x_t, x_t_prev, x_t_prev_pred, t
         M, L = mel.shape[2], mel.shape[1]
-        t = self._randint(B, dev)
         melc = mel.contiguous()
-        x_t_b = ops.diffuse(melc, t, self._bml(self._randn((B, 1, M, L), dev)), keep, buf)
-        x_prev_b = ops.diffuse(melc, (t - 1).contiguous(), self._bml(self._randn((B, 1, M, L), dev)), keep, buf)
-        post_noise = self._bml(self._randn((B, 1, M, L), dev))
+
+        def draw():   # the four random draws of one forward, in the reference's order (model/diffusion.py:203-209)
+            t_ = self._randint(B, dev)
+            x_t_ = ops.diffuse(melc, t_, self._bml(self._randn((B, 1, M, L), dev)), keep, buf)
+            x_prev_ = ops.diffuse(melc, (t_ - 1).contiguous(), self._bml(self._randn((B, 1, M, L), dev)), keep, buf)
+            return t_, x_t_, x_prev_, self._bml(self._randn((B, 1, M, L), dev))
+        pair_key = (mel.data_ptr(), mel._version, cond.data_ptr(), cond._version, mel_mask.data_ptr(), tuple(mel.shape),
+                    None if coarse_mel is None else coarse_mel.data_ptr(), None if spk is None else spk.data_ptr())
+        stash, self._pair_stash = self._pair_stash, None
         if grad:
             from .autograd import denoise_and_posterior
+            pre = None
+            if (stash is not None and stash["key"] == pair_key
+                    and self.denoise_fn.packed_weights(with_backward=True) is stash["packed"]
+                    and self.denoise_fn._packed_key == stash["packed_key"]):
+                # this forward was already launched next to the previous no-grad one (pair_forward): adopt its draws,
+                # its output and its saved activations
+                t, x_t_b, x_prev_b, post_noise = stash["draws"]
+                pre = (stash["x0"], stash["ws"]) if stash["ws"] is not None else None
+            else:
+                if stash is not None and stash["ws"] is not None:
+                    stash["ws"]._mg_busy = False      # never used: hand the workspace back
+                t, x_t_b, x_prev_b, post_noise = draw()
             x0c, xpp = denoise_and_posterior(self, x_t_b, t, cond_t, spk, post_noise, keep, clip_denoised,
-                                             coarse_mel if self.model == "shallow" else None)
+                                             coarse_mel if self.model == "shallow" else None, pre=pre)
             from .autograd import transpose_to_blm
             return (transpose_to_blm(x0c), ops.transpose_bml(x_t_b, True), ops.transpose_bml(x_prev_b, True),
                     transpose_to_blm(xpp), t)
-        x0 = self.denoise_fn.run(x_t_b, t, cond_t, spk)
+        if stash is not None and stash["ws"] is not None:
+            stash["ws"]._mg_busy = False
+        t, x_t_b, x_prev_b, post_noise = draw()
+        x0 = None
+        if self.pair_forward and self.denoise_fn.precision == "fp32":
+            # The GAN step runs this forward twice on the same weights -- here without gradient (train.py:133), then
+            # with (train.py:153), with fresh t / noise.  Draw the second set now (nothing else consumes randomness in
+            # between) and run both in one launch; the grad-enabled call that follows picks its half up above.
+            draws2 = draw()
+            both = self.denoise_fn.run_pair(x_t_b, t, draws2[1], draws2[0], cond_t, spk)
+            if both is not None:
+                x0 = both[0]
+            # (not a single-launch shape: the second forward still uses these draws, so that the random stream is
+            # consumed in the same order either way)
+            self._pair_stash = {"key": pair_key, "draws": draws2, "x0": None if both is None else both[1],
+                                "ws": None if both is None else both[2],
+                                "packed": self.denoise_fn._packed, "packed_key": self.denoise_fn._packed_key}
+        if x0 is None:
+            x0 = self.denoise_fn.run(x_t_b, t, cond_t, spk)
         if self.model != "shallow":
             xpp, x0c = ops.posterior_sample(x0, x_t_b, t, post_noise, keep, buf, clip=clip_denoised, want_x0c=True)
         else:

@@ -12,6 +12,8 @@ given conditioner, discriminator = JCUDiscriminator), with the reference's quirk
 The linguistic encoder is upstream of the path: `cond` is whatever produced
 the [B, L, 256] conditioner; its gradient is returned to the caller's graph as usual.
 """
+import os
+
 import torch
 
 from . import losses
@@ -65,6 +67,7 @@ class HotPathTrainer:
     # LSGAN and feature-matching sums as one launch each way (losses.weighted_means); False keeps one launch pair per
     # term through d_loss_fn / g_loss_fn / get_fm_loss (same values up to the order of the additions)
     fused_losses = True
+    pair_forwards = True      # False: the two generator forwards of a step as two launches
     grad_hook = None      # optional callable(name, bucket) after the gradient exchange, before clipping (tests, logging)
 
     def _update(self, params, bucket, opt):
@@ -104,8 +107,14 @@ class HotPathTrainer:
         # train.py:133 builds (and discards) the generator's autograd graph here; every output is detached
         # before use (train.py:135-137), so running it under no_grad gives identical results and skips
         # the activation saves of the grad-enabled forward.
-        with torch.no_grad():
-            x0, x_ts, x_prevs, x_prev_preds, t = G(mel, cond, spk, mel_pad_mask, coarse_mel)
+        # ... and it is launched TOGETHER with the G phase's forward below (same weights: only D is stepped in between;
+        # GaussianDiffusion.pair_forward): one grid of 64-frame tiles over both instead of two of 32-frame tiles
+        G.pair_forward = self.pair_forwards and os.environ.get("MG_PAIR_FORWARDS", "1") != "0"
+        try:
+            with torch.no_grad():
+                x0, x_ts, x_prevs, x_prev_preds, t = G(mel, cond, spk, mel_pad_mask, coarse_mel)
+        finally:
+            G.pair_forward = False
         x_ts_d, x_prevs_d, x_pp_d = x_ts.detach(), x_prevs.detach(), x_prev_preds.detach()
         spk_d = spk.detach() if spk is not None else None
         f_c, f_u, r_c, r_u = self._d_fake_and_real(x_ts_d, x_pp_d, x_prevs_d, spk_d, t)

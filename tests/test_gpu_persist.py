@@ -159,3 +159,50 @@ def test_more_tiles_than_slots_and_long_utterances(mg, manifest, tmp_path, monke
             one = den(x[B - 1:], t[B - 1:], cond[B - 1:], None)
         assert den.persist_status(B, L)["error"] == 0
         assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(one[0], a[B - 1])
+
+
+@pytest.mark.parametrize("ms", [False, True])
+@pytest.mark.parametrize("Bh,L", [(2, 131), (8, 1000), (3, 64)])
+def test_paired_forwards_match_separate_launches(mg, manifest, tmp_path, ms, Bh, L):
+    """mg_denoiser_fwd_pair (both generator forwards of a GAN step in one grid of 64-frame tiles): outputs of both
+    problems against separate launches, and the second problem's workspace through the ordinary backward -- input and
+    parameter gradients against a forward + backward that ran alone."""
+    from mixgan_tts_amd.autograd import DenoiserFn
+    den, _ = _den(mg, manifest, tmp_path, ms)
+    gen = torch.Generator(device="cuda").manual_seed(Bh * 1000 + L)
+    xa = torch.randn(Bh, 80, L, device="cuda", generator=gen)
+    xb = torch.randn(Bh, 80, L, device="cuda", generator=gen)
+    cond = torch.randn(Bh, 256, L, device="cuda", generator=gen)
+    spk = torch.randn(Bh, 256, device="cuda", generator=gen) if ms else None
+    ta = torch.randint(0, 1000, (Bh,), device="cuda", generator=gen)
+    tb = torch.randint(0, 1000, (Bh,), device="cuda", generator=gen)
+    go = torch.randn(Bh, 80, L, device="cuda", generator=gen)
+    params = [p for p in den._weight_table() if p is not None]
+
+    def backward_of(pre):
+        xg, cg = xb.clone().requires_grad_(), cond.clone().requires_grad_()
+        for p in params:
+            p.grad = None
+        out = DenoiserFn.apply(den, xg, tb, cg, spk, pre, *params)
+        (out * go).sum().backward()
+        return out.detach(), xg.grad, cg.grad, [p.grad.clone() for p in params]
+    with torch.no_grad():
+        ref_a = den.run(xa, ta, cond, spk).clone()
+    ref_b, ref_dx, ref_dc, ref_pg = backward_of(None)
+    with torch.no_grad():
+        both = den.run_pair(xa, ta, xb, tb, cond, spk)
+    assert both is not None
+    out_a, out_b, ws_b = both
+    assert den.persist_status(2 * Bh, L)["error"] == 0
+    assert_close(out_a.cpu(), ref_a.cpu(), TOL, "problem A (no save)")
+    assert_close(out_b.cpu(), ref_b.cpu(), TOL, "problem B (saving)")
+    got_b, dx, dc, pg = backward_of((out_b, ws_b))
+    assert torch.equal(got_b, out_b)
+    assert_close(dx.cpu(), ref_dx.cpu(), 5e-5, "d_x through the paired forward's workspace")
+    assert_close(dc.cpu(), ref_dc.cpu(), 5e-5, "d_cond")
+    for p, a, b in zip(params, pg, ref_pg):
+        if b.abs().max() > 0:
+            assert_close(a.cpu(), b.cpu(), 1e-4, "parameter gradient %s" % (tuple(p.shape),))
+    with torch.no_grad():   # twice in a row: tickets and halo tags re-arm
+        again = den.run_pair(xa, ta, xb, tb, cond, spk)
+    assert torch.equal(again[0], out_a) and torch.equal(again[1], out_b)

@@ -178,6 +178,30 @@ def test_trainer_fused_and_per_term_losses_agree(mg, manifest, tmp_path):
         assert_close(seen[True][1][name].cpu(), seen[False][1][name].cpu(), 2e-5, "bucket " + name)
 
 
+def test_trainer_paired_and_separate_forwards_agree(mg, manifest, tmp_path):
+    """HotPathTrainer.pair_forwards: the D-phase and G-phase generator forwards in one launch (the second one's t /
+    noise drawn early, in the same order) against two launches -- same logged losses, same gradients reaching the
+    optimizers, over two steps (the second step reuses both workspaces)."""
+    seen = {}
+    for paired in (True, False):
+        G, D, WG, WD, buf, mel, cond, pad, tapes, tr, mc = _setup(mg, manifest, tmp_path)
+        trainer = mg.HotPathTrainer(G, D, tr, mc)
+        trainer.pair_forwards = paired
+        grads = []
+        trainer.grad_hook = lambda name, bucket: grads.append((name, bucket.flat.clone()))
+        torch.manual_seed(5)
+        outs = [trainer.step(mel.cuda(), cond.cuda(), None, pad.cuda()) for _ in range(2)]
+        seen[paired] = (outs, grads)
+        assert G._pair_stash is None                     # consumed by the G-phase forward
+    for o1, o2 in zip(seen[True][0], seen[False][0]):
+        for k in ("d_loss", "adv_loss", "mel_loss", "fm_loss"):
+            a, b = o1[k].item(), o2[k].item()
+            assert abs(a - b) <= 5e-5 * max(1.0, abs(b)), k
+    for (n1, g1), (n2, g2) in zip(seen[True][1], seen[False][1]):
+        assert n1 == n2
+        assert_close(g1.cpu(), g2.cpu(), 1e-4, "bucket " + n1)
+
+
 def test_training_learns_a_solvable_task(mg, tmp_path):
     """End to end through every kernel of the step (both forwards, data and weight gradients, fused losses, flat clip +
     Adam, weight repack): with the normalised target in the conditioner's first 80 channels the denoiser can read x0
