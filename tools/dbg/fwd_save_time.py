@@ -18,3 +18,13 @@ def timeit(B, save, n=20):
     return e0.elapsed_time(e1) / n
 for B, save in [(8, False), (8, True), (16, False), (16, True)]:
     print("B=%d save=%s: %.3f ms" % (B, save, timeit(B, save)))
+x = torch.randn(8, 80, 1000, device="cuda"); x2 = torch.randn(8, 80, 1000, device="cuda")
+c = torch.randn(8, 256, 1000, device="cuda"); t = torch.randint(0, 4, (8,), device="cuda")
+def pair():
+    r = den.run_pair(x, t, x2, t, c, None); r[2]._mg_busy = False
+for _ in range(3): pair()
+torch.cuda.synchronize(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20): pair()
+e1.record(); torch.cuda.synchronize()
+print("pair 8+8 (second half saved): %.3f ms" % (e0.elapsed_time(e1) / 20))
