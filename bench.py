@@ -76,7 +76,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    # MG_BENCH_EXCHANGE=1 (train workload): a process group on a world of ONE, collectives forced -- the gradient
+    # exchange runs through RCCL as it does on 8 GPUs (a self-copy per collective), so comm_exposed_ms has a meaning
+    force_pg = world == 1 and args.workload == "train" and os.environ.get("MG_BENCH_EXCHANGE") == "1"
+    if force_pg and "MASTER_PORT" not in os.environ:
+        import socket
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+        s_.close()
+    if world > 1 or force_pg:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # MG_BENCH_SHARE_GPU=1 (rehearsal on a one-GPU box only): every rank on cuda:0 over gloo
@@ -292,6 +301,8 @@ def train_workload(args, mg, dev, dist, rank, world):
             p.copy_(torch.randn(p.shape, generator=gen) * (fan ** -0.5 if p.dim() > 1 else 0.1))
     G, D = G.to(dev), D.to(dev)
     trainer = mg.HotPathTrainer(G, D, tr, mc)
+    if dist is not None and world == 1:                 # MG_BENCH_EXCHANGE=1: run the collectives on the world of one
+        trainer.bucketG.always_exchange = trainer.bucketD.always_exchange = True
     rng = np.random.default_rng(1234 + rank)            # rank-distinct data shard
     mel = torch.from_numpy(rng.uniform(-11.5, 2.0, (B, L, MEL)).astype(np.float32)).to(dev)
     cond = torch.from_numpy(rng.standard_normal((B, L, 256)).astype(np.float32)).to(dev)
@@ -303,19 +314,35 @@ def train_workload(args, mg, dev, dist, rank, world):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        trainer.step(mel, cond, spk, pad)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = trainer.step(mel, cond, spk, pad)
-    sync()
-    dt = time.perf_counter() - t0
+    def timed(warm, steps):
+        for _ in range(warm):
+            trainer.step(mel, cond, spk, pad)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            o = trainer.step(mel, cond, spk, pad)
+        sync()
+        tm = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        return float(tm.item()), o
+
+    dt, out = timed(args.warmup, args.steps)
     assert all(torch.isfinite(v).all() for v in out.values())
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    trainer.check()                                     # a hand-off timeout would have poisoned the gradients
+    comm = {}
     if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        # the exposed cost of the gradient exchange: the same steps with the collectives skipped (everything else --
+        # gather, side stream, event hand-off, the division by the world size -- kept).  Measured AFTER the headline
+        # timing: without the all-reduce the replicas drift apart, which only this leg tolerates.
+        trainer.bucketG.stub = trainer.bucketD.stub = True
+        dt_stub, _ = timed(2, args.steps)
+        trainer.bucketG.stub = trainer.bucketD.stub = False
+        comm = {"comm_exposed_ms": round((dt - dt_stub) / args.steps * 1e3, 3),
+                "ms_per_step_without_collectives": round(dt_stub / args.steps * 1e3, 3),
+                "grad_bytes": {"G": trainer.bucketG.flat.numel() * 4, "D": trainer.bucketD.flat.numel() * 4,
+                               "G_early_chunk": (trainer._early[1] - trainer._early[0]) * 4 if trainer._early else 0},
+                "backend": dist.get_backend()}
     if rank == 0:
         # per step: 2 denoiser forwards + 1 backward (= 4 forward-equivalents), 4 D forwards + 2 backward passes
         flop = (4 * FLOP_PER_FRAME + 8 * 645504.0) * B * L * world
@@ -326,9 +353,11 @@ def train_workload(args, mg, dev, dist, rank, world):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: multi-speaker naive train step, batch %d/GPU (global %d), L=%d, "
                                    "T=4" % (B, B * world, L),
-                       "parallelism": "dp%d, flat-bucket gradient all-reduce (G 99 MB, D 8 MB) per optimizer" % world},
+                       "parallelism": "dp%d, flat-bucket gradient all-reduce per optimizer (G %.0f MB, its k=3 slice "
+                                      "behind an event inside the backward; D %.0f MB)"
+                                      % (world, trainer.bucketG.flat.numel() * 4e-6, trainer.bucketD.flat.numel() * 4e-6)},
             "samples_per_s": round(B * world * args.steps / dt, 2),
-            "approx_tflops": round(flop * args.steps / dt / 1e12, 1)}), flush=True)
+            "approx_tflops": round(flop * args.steps / dt / 1e12, 1), **comm}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -216,28 +216,44 @@ int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, const float 
  * p_sample (model/diffusion.py:121-129) as one call: x_0 = Denoiser.forward(x_t, t, cond, spk); clamp to [-1, 1] when
  * clip; x_prev = coef1[t] x_0 + coef2[t] x_t + (t > 0) exp(0.5 logvar[t]) * noise  (q_posterior + q_posterior_sample,
  * :104-119).  coef1 / coef2 / logvar: the posterior_mean_coef1 / posterior_mean_coef2 / posterior_log_variance_clipped
- * buffers [n_steps].  noise [B, M, L], or NULL: N(0,1) from Philox4x32-10 keyed by `seed` with a per-call counter kept
- * in the workspace (fresh noise on every call and on every replay of a captured graph).  x_prev [B, M, L] must not
- * alias x_t; x0_out (optional) receives the pre-clamp x_0.  On the fp32 inference path this is ONE kernel launch. */
+ * buffers [n_steps].  noise [B, M, L], or NULL: N(0,1) from Philox4x32-10 (the reference draws torch.randn_like per
+ * step, model/diffusion.py:32-35,118): key = `seed`, counter = (element index, noise_stream << 32 | launches completed
+ * on this workspace).  The launch count lives in the workspace, so every call and every replay of a captured graph
+ * draws fresh noise; `noise_stream` (its low 32 bits) must be unique per workspace instance within a process -- the
+ * caller numbers its workspaces -- so that two workspaces (another shape, a re-allocated one, another captured graph)
+ * never walk the same stream; ranks use different seeds.  x_prev [B, M, L] must not alias x_t; x0_out (optional)
+ * receives the pre-clamp x_0.  On the fp32 inference path this is ONE kernel launch. */
 int mg_denoiser_psample(const mg_denoiser_dims *d, const float *packed, const float *x_t, const int64_t *t,
                         const float *cond, const float *spk, const float *coef1, const float *coef2,
-                        const float *logvar, int n_steps, const float *noise, unsigned long long seed, int clip,
-                        float *x_prev, float *x0_out, float *workspace, size_t workspace_floats, int B, int L, int mode,
-                        void *stream);
+                        const float *logvar, int n_steps, const float *noise, unsigned long long seed,
+                        unsigned long long noise_stream, int clip, float *x_prev, float *x0_out, float *workspace,
+                        size_t workspace_floats, int B, int L, int mode, void *stream);
 /* Both generator forwards of a GAN training step (train.py:133 and :153 -- same weights, different t / noise) as ONE
  * launch of 64-frame tiles: problem A (x_tA, tA -> outA; nothing kept) is the D phase's no-grad forward, problem B
  * (x_tB, tB -> outB) the G phase's: its layer activations land in wsB exactly as mg_denoiser_fwd(MG_FWD_SAVE) leaves
- * them, so mg_denoiser_bwd runs on (x_tB, tB, wsB) unchanged.  Bh utterances per problem over the same cond [Bh, H, L]
- * and spk.  wsA: mg_denoiser_workspace_floats(dims, 2 * Bh, L, 0) floats (zero before its first use, like every
+ * them, so mg_denoiser_bwd runs on (x_tB, tB, wsB) unchanged.  Bh utterances per problem; problem A reads cond [Bh, H, L]
+ * and spk, problem B condB / spkB (NULL = the same as A's: the reference runs its train-mode linguistic encoder once per
+ * model call, so the two phases see different conditioners unless the encoder is deterministic).  wsA: mg_denoiser_workspace_floats(dims, 2 * Bh, L, 0) floats (zero before its first use, like every
  * forward workspace); wsB: mg_denoiser_workspace_floats(dims, Bh, L, 1).  packed: with the backward packs or without.
  * MG_ERR_SHAPE when the single-launch kernel does not take the shape -- run the two forwards separately then. */
 int mg_denoiser_fwd_pair(const mg_denoiser_dims *dims, const float *packed, const float *x_tA, const int64_t *tA,
-                         const float *x_tB, const int64_t *tB, const float *cond, const float *spk, float *outA,
-                         float *outB, float *wsA, size_t wsA_floats, float *wsB, size_t wsB_floats, int Bh, int L,
-                         void *stream);
+                         const float *x_tB, const int64_t *tB, const float *cond, const float *spk, const float *condB,
+                         const float *spkB, float *outA, float *outB, float *wsA, size_t wsA_floats, float *wsB,
+                         size_t wsB_floats, int Bh, int L, void *stream);
+/* Failure reporting of the single-launch kernels (mg_denoiser_fwd / _psample / _fwd_pair / _bwd).  Their workgroups
+ * hand halo columns to each other; every wait is bounded, and when one gives up (another tenant holding the GPU's
+ * workgroup slots for seconds) the launch drains instead of hanging, and
+ *   - the workspace's sticky error word is set: that launch, and every later one on the same workspace, writes NaN
+ *     instead of its output (forward: out / x_prev; backward: d x_t and the input-projection gradients);
+ *   - a process-wide word in pinned host memory receives the code (forward: 1 + layer, backward: 0x100 + layer).
+ * mg_persist_error(clear) returns that word without synchronising anything (0 = no failure so far; after a stream
+ * synchronisation it is exact for all work before it) and resets it when `clear`.  A caller that sees it non-zero must
+ * discard the workspaces in use (their sticky words stay set).  Test hooks, read per call: MG_PERSIST_SPIN_LIMIT (polls
+ * before giving up), MG_PERSIST_FLAGS bit 1 (a tile withholds one hand-off). */
+unsigned mg_persist_error(int clear);
 /* Copies the single-launch forward's counter words {ticket, error, launches, workgroups done} of a (B, L, no-save)
  * workspace to host_out4 and synchronises the stream: error != 0 means a neighbour hand-off timed out (the launch
- * drained instead of hanging; its output is invalid). */
+ * drained instead of hanging; its output is NaN). */
 int mg_denoiser_persist_status(const mg_denoiser_dims *d, const float *workspace, int B, int L, unsigned *host_out4,
                                void *stream);
 
@@ -256,6 +272,16 @@ int mg_denoiser_bwd(const mg_denoiser_dims *d, const float *packed, const float 
                     const float *x_t, const float *cond, const float *spk, float *workspace,
                     float *bwd_workspace, size_t bwd_workspace_floats, float *const *grads,
                     float *d_x_t, float *d_cond, float *d_spk, int B, int L, void *stream);
+/* Same; conv3_grads_done (a hipEvent_t, or NULL) is recorded on `stream` right behind the launches that produce the
+ * conv_layer weight and bias gradients of all layers (entries j=0/1: a third of the generator's gradient bytes), 0.6 ms
+ * of GPU work before the last launch of the backward at B=8, L=1000 -- a data-parallel caller starts the all-reduce of
+ * that slice behind the event while the remaining gradients are still being computed (train.py has no such exchange:
+ * the reference is single-device). */
+int mg_denoiser_bwd_staged(const mg_denoiser_dims *d, const float *packed, const float *g_out,
+                           const float *x_t, const float *cond, const float *spk, float *workspace,
+                           float *bwd_workspace, size_t bwd_workspace_floats, float *const *grads,
+                           float *d_x_t, float *d_cond, float *d_spk, int B, int L, void *conv3_grads_done,
+                           void *stream);
 
 /* ------------------------------------------------------------------ pieces of autograd around the GEMMs
  * dpre = dy * act'(.) written through the saved OUTPUT y = act(pre) (ReLU / LeakyReLU(0.2) / tanh). */

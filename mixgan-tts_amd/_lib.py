@@ -17,13 +17,13 @@ EXPORTS = (
     "mg_conv1d_wgrad_grouped_scratch_floats", "mg_conv1d_wgrad_grouped_bias", "mg_rowsum",
     "mg_diffuse_fwd", "mg_posterior_sample_fwd", "mg_posterior_sample_bwd", "mg_spec_affine", "mg_transpose_bml",
     "mg_denoiser_packed_floats", "mg_denoiser_pack", "mg_denoiser_workspace_floats", "mg_denoiser_fwd",
-    "mg_denoiser_bwd_workspace_floats", "mg_denoiser_bwd",
+    "mg_denoiser_bwd_workspace_floats", "mg_denoiser_bwd", "mg_denoiser_bwd_staged",
     "mg_profile_begin", "mg_profile_begin_sampled", "mg_profile_end", "mg_transpose_bml_strided", "mg_act_bwd", "mg_upsample_zero",
     "mg_step_mlp_fwd", "mg_step_mlp_bwd", "mg_linear_small_fwd", "mg_linear_small_bwd",
     "mg_loss_sum", "mg_loss_grad", "mg_mel_l1_fwd", "mg_mel_l1_bwd", "mg_attention_fwd", "mg_attention_fwd_f16", "mg_layernorm_cm_fwd",
     "mg_length_regulate_fwd", "mg_length_regulate_bwd", "mg_word_pool_fwd", "mg_word_pool_bwd", "mg_mapping_mask",
     "mg_rel_coef", "mg_resblock_fwd", "mg_gate_bwd", "mg_mish_fwd", "mg_mish_bwd", "mg_step_embed",
-    "mg_denoiser_psample", "mg_denoiser_persist_status", "mg_denoiser_fwd_pair",
+    "mg_denoiser_psample", "mg_denoiser_persist_status", "mg_persist_error", "mg_denoiser_fwd_pair",
     "mg_grad_norm_scratch_floats", "mg_grad_norm", "mg_adam_flat",
     "mg_multi_loss_scratch_floats", "mg_multi_loss_fwd", "mg_multi_loss_bwd",
 )
@@ -116,9 +116,10 @@ def _declare(L):
         "mg_denoiser_pack": (i, [dp, vp, vp, vp, i, vp]),
         "mg_denoiser_bwd_workspace_floats": (sz, [dp, i, i]),
         "mg_denoiser_bwd": (i, [dp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, i, i, vp]),
+        "mg_denoiser_bwd_staged": (i, [dp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp, i, i, vp, vp]),
         "mg_denoiser_workspace_floats": (sz, [dp, i, i, i]),
         "mg_denoiser_fwd": (i, [dp, vp, vp, vp, vp, vp, vp, vp, sz, i, i, i, vp]),
-        "mg_denoiser_fwd_pair": (i, [dp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, sz, i, i, vp]),
+        "mg_denoiser_fwd_pair": (i, [dp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, sz, i, i, vp]),
         "mg_transpose_bml_strided": (i, [vp] * 5 + [i, i, i, i, i, ctypes.c_long, vp]),
         "mg_act_bwd": (i, [vp, vp, vp, i, sz, vp]),
         "mg_upsample_zero": (i, [vp, vp, i, i, i, i, vp]),
@@ -150,7 +151,9 @@ def _declare(L):
         "mg_mish_fwd": (i, [vp, vp, sz, vp]),
         "mg_mish_bwd": (i, [vp, vp, vp, sz, vp]),
         "mg_step_embed": (i, [vp, vp, vp, i, i, vp]),
-        "mg_denoiser_psample": (i, [dp] + [vp] * 8 + [i, vp, ctypes.c_ulonglong, i, vp, vp, vp, sz, i, i, i, vp]),
+        "mg_denoiser_psample": (i, [dp] + [vp] * 8 + [i, vp, ctypes.c_ulonglong, ctypes.c_ulonglong, i, vp, vp, vp, sz,
+                                    i, i, i, vp]),
+        "mg_persist_error": (ctypes.c_uint, [i]),
         "mg_denoiser_persist_status": (i, [dp, vp, i, i, vp, vp]),
         "mg_profile_begin": (i, [i]),
         "mg_profile_begin_sampled": (i, [i, i]),

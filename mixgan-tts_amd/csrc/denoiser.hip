@@ -16,6 +16,7 @@
 #include "denoiser_persist16.h"
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
 
 // ------------------------------------------------------------------------------------------ epilogues
 struct EpiCond {
@@ -465,12 +466,72 @@ extern "C" int mg_resblock_fwd(const float *x, const float *cond, const float *w
 struct PostSample {
     const float *coef1, *coef2, *logvar;   // [n_steps] posterior_mean_coef1/2, posterior_log_variance_clipped
     const float *noise;                    // [B, M, L] or NULL (in-kernel Philox)
-    unsigned long long seed;
+    unsigned long long seed, noise_stream;
     float *x0_out;                         // optional pre-clamp x_0
     int n_steps, clip;
 };
 
-static std::atomic<unsigned> g_persist_epoch{0};
+// ---- host side of the persistent kernels' failure reporting and slot accounting (declared in denoiser_common.h)
+static unsigned *g_host_err = nullptr, *g_host_err_dev = nullptr;
+static std::atomic<int> g_host_err_state{0};   // 0 untried, 1 ready, -1 unavailable
+
+unsigned *mg_host_err_device_ptr()
+{
+    int s = g_host_err_state.load();
+    if (s == 0) {
+        static std::atomic_flag busy = ATOMIC_FLAG_INIT;
+        if (busy.test_and_set()) return nullptr;   // another thread is allocating: this launch reports through the workspace only
+        void *h = nullptr, *dptr = nullptr;
+        // not a stream operation; under stream capture it fails (cleanly) and is retried on the next launch
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && h) {
+            std::memset(h, 0, 64);
+            if (hipHostGetDevicePointer(&dptr, h, 0) == hipSuccess && dptr) {
+                g_host_err = (unsigned *)h;
+                g_host_err_dev = (unsigned *)dptr;
+                g_host_err_state.store(1);
+            } else {
+                (void)hipHostFree(h);
+            }
+        }
+        (void)hipGetLastError();   // a failed attempt must not surface as a later launch's error
+        busy.clear();
+        s = g_host_err_state.load();
+    }
+    return s == 1 ? g_host_err_dev : nullptr;
+}
+
+extern "C" unsigned mg_persist_error(int clear)
+{
+    if (g_host_err_state.load() != 1) {
+        (void)mg_host_err_device_ptr();
+        if (g_host_err_state.load() != 1) return 0u;
+    }
+    const unsigned v = __atomic_load_n(g_host_err, __ATOMIC_ACQUIRE);
+    if (clear && v) __atomic_store_n(g_host_err, 0u, __ATOMIC_RELEASE);
+    return v;
+}
+
+int mg_device_cus()
+{
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cus[dev].load();
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev].store(n);
+    }
+    return n;
+}
+
+unsigned mg_persist_spin_limit()
+{
+    if (const char *e = std::getenv("MG_PERSIST_SPIN_LIMIT")) {   // read per call: a test shrinks it for one launch
+        const long v = std::atol(e);
+        if (v > 0) return (unsigned)v;
+    }
+    return DP_SPIN_LIMIT;
+}
 // tools only (tools/persist_timeline.py): when set, launches with float4 staging run the TIMING instantiation, which
 // writes lane 0's cycle stamps [tiles][NL + 2][12] here.  Not declared in the public header.
 static unsigned long long *g_persist_dbg = nullptr;
@@ -509,14 +570,14 @@ extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, c
 
 extern "C" int mg_denoiser_psample(const mg_denoiser_dims *d, const float *packed, const float *x_t, const int64_t *t,
                                    const float *cond, const float *spk, const float *coef1, const float *coef2,
-                                   const float *logvar, int n_steps, const float *noise, unsigned long long seed, int clip,
-                                   float *x_prev, float *x0_out, float *ws, size_t ws_floats, int B, int L, int mode,
-                                   void *stream)
+                                   const float *logvar, int n_steps, const float *noise, unsigned long long seed,
+                                   unsigned long long noise_stream, int clip, float *x_prev, float *x0_out, float *ws,
+                                   size_t ws_floats, int B, int L, int mode, void *stream)
 {
     if (!coef1 || !coef2 || !logvar || n_steps <= 0 || !x_prev) return MG_ERR_ARG;
     if (mode & MG_FWD_SAVE) return MG_ERR_ARG;
     if (x_prev == x_t) return MG_ERR_ARG;   // the posterior reads x_t after other tiles have written x_prev
-    const PostSample ps{coef1, coef2, logvar, noise, seed, x0_out, n_steps, clip};
+    const PostSample ps{coef1, coef2, logvar, noise, seed, noise_stream, x0_out, n_steps, clip};
     return denoiser_forward(d, packed, x_t, t, cond, spk, x_prev, ws, ws_floats, B, L, mode, &ps, stream);
 }
 
@@ -534,10 +595,11 @@ extern "C" int mg_denoiser_persist_status(const mg_denoiser_dims *d, const float
 __global__ void psample_tail_kernel(const float *__restrict__ x0, const float *__restrict__ x_t, const int64_t *__restrict__ t,
                                     const float *__restrict__ coef1, const float *__restrict__ coef2,
                                     const float *__restrict__ logvar, const float *__restrict__ noise,
-                                    unsigned long long seed, const unsigned *__restrict__ launch_ctr, float *__restrict__ out,
+                                    unsigned long long seed, unsigned long long noise_stream,
+                                    const unsigned *__restrict__ launch_ctr, float *__restrict__ out,
                                     float *__restrict__ x0_out, int n_steps, int clip, size_t per_sample, size_t n)
 {
-    const unsigned long long off = launch_ctr ? launch_ctr[0] : 0ull;
+    const unsigned long long off = (noise_stream << 32) | (launch_ctr ? (unsigned long long)launch_ctr[0] : 0ull);
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const size_t b = e / per_sample;
         long tb = (long)t[b];
@@ -559,7 +621,7 @@ static int psample_tail(const PostSample &ps, const float *x0, const float *x_t,
     const size_t per = (size_t)M * L, n = per * B;
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(psample_tail_kernel, dim3(blocks), dim3(256), 0, st, x0, x_t, t, ps.coef1, ps.coef2, ps.logvar,
-                       ps.noise, ps.seed, sync + 2, out, ps.x0_out, ps.n_steps, ps.clip, per, n);
+                       ps.noise, ps.seed, ps.noise_stream, sync + 2, out, ps.x0_out, ps.n_steps, ps.clip, per, n);
     MG_LAUNCH_CHECK();
     if (!ps.noise) {   // the launch counter is the Philox offset: one fresh stream per call
         hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(1), 0, st, sync + 2);
@@ -617,11 +679,12 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
     if (nt == 16 && mg_cdiv(L, 16) > 128) nt = 32;
     if (nt != 32) wide32 = false;
     const int tiles_per_b = mg_cdiv(L, nt);
-    const int chain_cap = (nt == 64 || wide32) ? 64 : 128;   // a quarter of the 256 / 512 slots
+    // a quarter of the chip's workgroup slots (one per CU for the 8-wave forms, two for the 4-wave ones)
+    const int chain_cap = (nt == 64 || wide32) ? mg_device_cus() / 4 : mg_device_cus() / 2;
     if (fused && !no_persist && !split && M <= 96 && NL >= 3 && tiles_per_b <= chain_cap) {
         PersistArgs a;
         a.b_split = 0;
-        a.x_t2 = a.hvec2 = a.dvec2 = nullptr;
+        a.x_t2 = a.hvec2 = a.dvec2 = a.cond2 = nullptr;
         a.out2 = nullptr;
         a.x_t = x_t;
         a.cond = cond;
@@ -658,10 +721,12 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
         a.logvar = post ? post->logvar : nullptr;
         a.noise = post ? post->noise : nullptr;
         a.seed = post ? post->seed : 0ull;
+        a.noise_stream = post ? post->noise_stream : 0ull;
         a.x0_out = post ? post->x0_out : nullptr;
         a.gran = reinterpret_cast<dp_u64 *>(ws + w.gran);
         a.sync = reinterpret_cast<unsigned *>(ws + w.sync);
-        a.epoch_base = g_persist_epoch.fetch_add((unsigned)NL + 1u);
+        a.host_err = mg_host_err_device_ptr();
+        a.spin_limit = mg_persist_spin_limit();
         a.B = B;
         a.L = L;
         a.M = M;
@@ -853,10 +918,12 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
 // unchanged.  64-frame tiles: 2 Bh ceil(L/64) workgroups.  Returns MG_ERR_SHAPE when the single-launch kernel does
 // not take the shape (the caller then runs the two forwards separately).
 extern "C" int mg_denoiser_fwd_pair(const mg_denoiser_dims *d, const float *packed, const float *x_tA, const int64_t *tA,
-                                    const float *x_tB, const int64_t *tB, const float *cond, const float *spk, float *outA,
-                                    float *outB, float *wsA, size_t wsA_floats, float *wsB, size_t wsB_floats, int Bh, int L,
-                                    void *stream)
+                                    const float *x_tB, const int64_t *tB, const float *cond, const float *spk,
+                                    const float *condB, const float *spkB, float *outA, float *outB, float *wsA,
+                                    size_t wsA_floats, float *wsB, size_t wsB_floats, int Bh, int L, void *stream)
 {
+    if (!condB) condB = cond;
+    if (!spkB) spkB = spk;
     MG_TRY(den_check(d));
     if (!packed || !x_tA || !tA || !x_tB || !tB || !cond || !outA || !outB || !wsA || !wsB) return MG_ERR_ARG;
     if (d->multi_speaker && !spk) return MG_ERR_ARG;
@@ -864,13 +931,13 @@ extern "C" int mg_denoiser_fwd_pair(const mg_denoiser_dims *d, const float *pack
     const int C = d->channels, H = d->cond_channels, M = d->mel_bins, NL = d->n_layers;
     const int tiles_per_b = mg_cdiv(L, 64);
     const char *pe = std::getenv("MG_DENOISER_PERSIST");
-    if ((pe && pe[0] == '0') || C != RB_C || H != RB_C || M > 96 || NL < 3 || tiles_per_b > 64) return MG_ERR_SHAPE;
+    if ((pe && pe[0] == '0') || C != RB_C || H != RB_C || M > 96 || NL < 3 || tiles_per_b > mg_device_cus() / 4) return MG_ERR_SHAPE;
     const DenWs wA = den_ws(d, 2 * Bh, L, 0), wB = den_ws(d, Bh, L, 1);
     if (wsA_floats < wA.total || wsB_floats < wB.total) return MG_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const DenLayout o = den_layout(d, 0);
     MG_TRY(den_step_vectors(d, o, packed, tA, spk, wsA, wA, Bh, st));
-    MG_TRY(den_step_vectors(d, o, packed, tB, spk, wsB, wB, Bh, st));
+    MG_TRY(den_step_vectors(d, o, packed, tB, spkB, wsB, wB, Bh, st));
     PersistArgs a;
     a.x_t = x_tA;
     a.x_t2 = x_tB;
@@ -882,6 +949,7 @@ extern "C" int mg_denoiser_fwd_pair(const mg_denoiser_dims *d, const float *pack
     a.dvec2 = wsB + wB.dvec;
     a.b_split = Bh;
     a.cond = cond;
+    a.cond2 = condB;
     a.in_w = packed + o.in_w;
     a.in_b = packed + o.in_b;
     a.layers = packed + o.layers;
@@ -901,11 +969,12 @@ extern "C" int mg_denoiser_fwd_pair(const mg_denoiser_dims *d, const float *pack
     a.p_wc = a.p_w3 = a.p_wo = 0;
     a.t = nullptr;
     a.coef1 = a.coef2 = a.logvar = a.noise = nullptr;
-    a.seed = 0ull;
+    a.seed = a.noise_stream = 0ull;
     a.x0_out = nullptr;
     a.gran = reinterpret_cast<dp_u64 *>(wsA + wA.gran);
     a.sync = reinterpret_cast<unsigned *>(wsA + wA.sync);
-    a.epoch_base = g_persist_epoch.fetch_add((unsigned)NL + 1u);
+    a.host_err = mg_host_err_device_ptr();
+    a.spin_limit = mg_persist_spin_limit();
     a.B = 2 * Bh;
     a.L = L;
     a.M = M;
@@ -925,7 +994,7 @@ extern "C" int mg_denoiser_fwd_pair(const mg_denoiser_dims *d, const float *pack
     a.tnh_save = wsB + wB.tnh;
     a.act_stride = wB.act_stride;
     a.flags = 0;
-    const bool vec4 = (L % 4 == 0) && (((uintptr_t)cond & 15) == 0);
+    const bool vec4 = (L % 4 == 0) && (((uintptr_t)cond & 15) == 0) && (((uintptr_t)condB & 15) == 0);
     dim3 grid((unsigned)(tiles_per_b * 2 * Bh));
     if (vec4) hipLaunchKernelGGL((denoiser_persist_kernel<64, true, false, true>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((denoiser_persist_kernel<64, false, false, true>), grid, dim3(512), 0, st, a);

@@ -185,6 +185,15 @@ extern "C" int mg_denoiser_bwd(const mg_denoiser_dims *d, const float *packed, c
                                float *const *grads, float *d_x_t, float *d_cond, float *d_spk, int B, int L,
                                void *stream)
 {
+    return mg_denoiser_bwd_staged(d, packed, g_out, x_t, cond, spk, ws, bws, bws_floats, grads, d_x_t, d_cond, d_spk, B, L,
+                                  nullptr, stream);
+}
+
+extern "C" int mg_denoiser_bwd_staged(const mg_denoiser_dims *d, const float *packed, const float *g_out, const float *x_t,
+                                      const float *cond, const float *spk, float *ws, float *bws, size_t bws_floats,
+                                      float *const *grads, float *d_x_t, float *d_cond, float *d_spk, int B, int L,
+                                      void *conv3_grads_done, void *stream)
+{
     MG_TRY(den_check(d));
     if (!packed || !g_out || !x_t || !cond || !ws || !bws || !grads) return MG_ERR_ARG;
     if (d->multi_speaker && !spk) return MG_ERR_ARG;
@@ -247,10 +256,9 @@ extern "C" int mg_denoiser_bwd(const mg_denoiser_dims *d, const float *packed, c
     // dout = [dx_l / sqrt2 ; dskip]; slot l+1 of dx_all holds the dx that ENTERS layer l, slot l the one it produces
     // One persistent launch (denoiser_bwd_persist.h) when the shapes allow; MG_DENOISER_PERSIST=0 keeps the two
     // generic conv launches per layer.
-    static std::atomic<unsigned> bwd_epoch{0};
     const char *pe = std::getenv("MG_DENOISER_PERSIST");
     const int tiles_per_b = mg_cdiv(L, 32);
-    const bool persist = !(pe && pe[0] == '0') && C == RB_C && NL >= 3 && tiles_per_b <= 64;
+    const bool persist = !(pe && pe[0] == '0') && C == RB_C && NL >= 3 && tiles_per_b <= mg_device_cus() / 4;
     if (persist) {
         BwdPersistArgs pa;
         pa.dout = dout;
@@ -266,7 +274,8 @@ extern "C" int mg_denoiser_bwd(const mg_denoiser_dims *d, const float *packed, c
         pa.dh_all = dh_all;
         pa.gran = reinterpret_cast<dp_u64 *>(bws + bw.gran);
         pa.sync = reinterpret_cast<unsigned *>(bws + bw.sync);
-        pa.epoch_base = bwd_epoch.fetch_add((unsigned)NL + 1u);
+        pa.host_err = mg_host_err_device_ptr();
+        pa.spin_limit = mg_persist_spin_limit();
         pa.B = B;
         pa.L = L;
         pa.NL = NL;
@@ -305,6 +314,10 @@ extern "C" int mg_denoiser_bwd(const mg_denoiser_dims *d, const float *packed, c
             MG_TRY(wgrad_grouped(NL, dz_all, dz_bs, (long)(2 * CL), h_all, (long)CL, act_gs, LG(0, 0), (long)2 * C * C * 3, scr,
                                  B, 2 * C, C, L, 3, 1, st, fold3 ? LG(0, 1) : nullptr, (long)(2 * C)));
         if (LG(0, 1) && !fold3) MG_TRY(rowsum(dz_all, 0, B, NL * 2 * C, L, LG(0, 1), nullptr, 1.f, st));
+        if (conv3_grads_done) {   // the largest gradient array is final from here on: its exchange may start
+            const hipError_t ee = hipEventRecord((hipEvent_t)conv3_grads_done, st);
+            if (ee != hipSuccess) return (int)ee;
+        }
         if (LG(0, 5)) {   // output conv: rows < C see dx_l (slot l+1), rows >= C the layer-independent dskip
             MG_TRY(wgrad_grouped(NL, dx_all + CL, dx_bs, (long)CL, g_all, (long)CL, act_gs, LG(0, 5), (long)2 * C * C, scr, B, C,
                                  C, L, 1, 0, st, foldo ? LG(0, 6) : nullptr, (long)(2 * C)));

@@ -28,8 +28,9 @@ struct BwdPersistArgs {
     float *dx_all;           // [B][(NL+1)*C][L]: slot l receives the dx layer l produces (/sqrt2)
     float *dh_all;           // [B][NL*C][L]
     dp_u64 *gran;            // [2 parity][tiles][2 sides][512]
-    unsigned *sync;          // as in the forward: [0] ticket, [1] error, [3] done
-    unsigned epoch_base;
+    unsigned *sync;          // as in the forward: [0] ticket, [1] error (sticky), [2] launches completed, [3] done
+    unsigned *host_err;      // pinned host word (or NULL)
+    unsigned spin_limit;
     int B, L, NL, tiles_per_b;
 };
 
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(512, 2) void denoiser_bwd_persist_kernel(BwdPersist
 {
     constexpr int NT = 32, ND = NT, NZ = NT + 2;
     __shared__ __attribute__((aligned(16))) float lds[2 * RB_C * (ND + NZ)];
-    __shared__ unsigned s_tile, s_dead;
+    __shared__ unsigned s_tile, s_dead, s_launch;
     float *douT = lds;                       // 512 channels x ND columns
     float *dzT = lds + 2 * RB_C * ND;        // 512 channels x NZ columns
 
@@ -65,10 +66,12 @@ __global__ __launch_bounds__(512, 2) void denoiser_bwd_persist_kernel(BwdPersist
     const int n_tiles = a.tiles_per_b * a.B;
     if (tid == 0) {
         s_tile = __hip_atomic_fetch_add(a.sync, 1u, DP_RLX_AGENT);   // tickets in START order
+        s_launch = __hip_atomic_load(a.sync + 2, DP_RLX_AGENT);     // advanced only after every workgroup has exited
         s_dead = 0u;
     }
     __syncthreads();
     const int tile = (int)(s_tile % (unsigned)n_tiles);
+    const unsigned launch_no = s_launch;
     const int b = tile / a.tiles_per_b, jt = tile - b * a.tiles_per_b;
     const int l0 = jt * NT;
     const bool has_left = jt > 0, has_right = jt + 1 < a.tiles_per_b;
@@ -109,12 +112,11 @@ __global__ __launch_bounds__(512, 2) void denoiser_bwd_persist_kernel(BwdPersist
     dp_store_block<ND>(douT, ch0, c32, hh, [&](int) { return 0.f; });
 
     dp_gu64 *const gran = (dp_gu64 *)a.gran;
-    dp_gu32 *const err = (dp_gu32 *)(a.sync + 1);
     const size_t dz_bs = (size_t)NL * 2 * CL, dx_bs = (size_t)(NL + 1) * CL, dh_bs = (size_t)NL * CL;
 
     for (int l = NL - 1; l >= 0; --l) {
         const float *bp = a.blayers + (size_t)l * a.blayer_stride;
-        const unsigned epoch = a.epoch_base + (unsigned)(NL - 1 - l) + 1u;
+        const unsigned epoch = launch_no * ((unsigned)NL + 1u) + (unsigned)(NL - 1 - l) + 1u;   // never repeats on a workspace
         const int par = l & 1;
         // saved sigmoid / tanh of this wave's channels: loaded now, used after GEMM A
         float sg[16], th[16];
@@ -195,9 +197,9 @@ __global__ __launch_bounds__(512, 2) void denoiser_bwd_persist_kernel(BwdPersist
                         ok &= (unsigned)(x >> 32) == epoch;
                     }
                     if (__all(ok)) break;
-                    if (++spins > DP_SPIN_LIMIT) {
+                    if (++spins > a.spin_limit) {
                         if (lane == 0) {
-                            __hip_atomic_store(err, 0x100u + (unsigned)l, DP_RLX_AGENT);
+                            dp_fail(a.sync, a.host_err, 0x100u + (unsigned)l);
                             s_dead = 1u;
                         }
                         break;
@@ -225,16 +227,20 @@ __global__ __launch_bounds__(512, 2) void denoiser_bwd_persist_kernel(BwdPersist
             }
         }
     }
+    // a hand-off timed out in this launch: poison what the input-projection backward and d x_t are computed from
+    // (and with them the gradient norm), so that the failed backward cannot pass for a result
+    const bool bad = dp_failed(a.sync);
     if (fvalid) {   // what the input-projection backward reads: dout rows < C = dx_0 / sqrt2
         float *ob = a.dout + (size_t)b * 2 * CL;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ob[(size_t)row_of(r) * L + f] = dxs[r];
+        for (int r = 0; r < 16; ++r) ob[(size_t)row_of(r) * L + f] = bad ? __builtin_nanf("") : dxs[r];
     }
     if (tid == 0) {
         const unsigned done = __hip_atomic_fetch_add(a.sync + 3, 1u, DP_RLX_AGENT);
         if (done == (unsigned)n_tiles - 1u) {
             __hip_atomic_store(a.sync + 3, 0u, DP_RLX_AGENT);
             __hip_atomic_store(a.sync, 0u, DP_RLX_AGENT);
+            __hip_atomic_fetch_add(a.sync + 2, 1u, DP_RLX_AGENT);
         }
     }
 }

@@ -4,6 +4,17 @@
 #pragma once
 #include "conv_mfma.h"
 
+// ------------------------------------------------------------------------------------------ single-launch kernels: host side
+// (defined in denoiser.hip; used by the forward and backward launchers)
+// Compute units of the current device (the forward-progress argument of the persistent kernels counts slots).
+int mg_device_cus();
+// Device-visible address of the library's host-pinned error word, or NULL when it cannot be allocated (then only the
+// workspace's own sticky word and the NaN poison report a failure).  64 bytes of pinned HOST memory, allocated on first
+// use -- the only allocation the library makes.
+unsigned *mg_host_err_device_ptr();
+// polls a hand-off wait makes before it gives up: DP_SPIN_LIMIT, or MG_PERSIST_SPIN_LIMIT (tests)
+unsigned mg_persist_spin_limit();
+
 // ------------------------------------------------------------------------------------------ packed blob
 struct DenLayout {
     // offsets in floats into the packed blob

@@ -23,14 +23,19 @@
 //      both k-interleaved (dp_at): a lane's B fragments of a k-group are one ds_read_b128
 // Forward progress: tiles are handed out by atomic tickets in START order, so a workgroup only ever waits for workgroups
 // that have started or will start as soon as a slot frees; an utterance's tiles are consecutive tickets, and the launcher
-// uses this kernel only when an utterance's chain fits in a quarter of the chip's slots.  Every spin is bounded (a
-// timeout sets an error word and lets the kernel drain).
+// uses this kernel only when an utterance's chain fits in a quarter of the chip's slots.  Every spin is bounded: a
+// timeout sets the workspace's sticky error word and a host-visible one (pinned memory, mg_persist_error), the kernel
+// drains, and every workgroup that finishes with the error word set writes NaN instead of its output tile -- a failed
+// launch cannot be mistaken for a result.
+// Hand-off tags and the Philox offset derive from the launch counter kept IN the workspace (sync[2]), so a captured
+// graph's replays get fresh tags and fresh noise without any host-side argument changing.
 #pragma once
 #include "common.h"
 #include "resblock_fused.h"
 
 #define DP_SPIN_LIMIT (1u << 21)   // x ~2 us per poll: seconds, then the error word is set and the kernel drains
 #define DP_F_ROLES 1               // NT = 32: two ticket queues by hardware wave slot (see the kernel)
+#define DP_F_WITHHOLD 2            // test hook: the second tile of every utterance never sends its left edge column
 
 typedef unsigned long long dp_u64;
 typedef __attribute__((address_space(1))) dp_u64 dp_gu64;
@@ -50,13 +55,15 @@ struct PersistArgs {
     // fused p_sample tail (post != 0): out = c1[t] clamp(x0) + c2[t] x_t + (t > 0) exp(0.5 lv[t]) noise
     const int64_t *t;                     // [B]
     const float *coef1, *coef2, *logvar;  // [T]
-    const float *noise;                   // [B, M, L] or NULL: then Philox4x32-10, key = seed, counter = (element, launch)
-    unsigned long long seed;
+    const float *noise;                   // [B, M, L] or NULL: then Philox4x32-10, key = seed,
+    unsigned long long seed;              //   counter = (element index, noise_stream << 32 | launches on this workspace)
+    unsigned long long noise_stream;      // unique per workspace instance (host-assigned)
     float *x0_out;                        // optional [B, M, L]: the pre-clamp x_0 when post != 0
     dp_u64 *gran;                         // [2 parity][tiles][2 sides][256] {tag << 32 | float bits}
     unsigned *sync;                       // [0] / [16] tickets, [1] error (sticky), [2] launches completed, [3] workgroups done;
                                           // zero once at allocation: the last workgroup out re-arms [0], [16] and [3]
-    unsigned epoch_base;
+    unsigned *host_err;                   // pinned host word (or NULL): receives the error code at system scope
+    unsigned spin_limit;                  // polls before a hand-off wait gives up (DP_SPIN_LIMIT; tests shrink it)
     // SAVE instantiation (training forward): what mg_denoiser_bwd consumes, all [B, 256, L]
     float *x0_save, *y_save, *skip_save;  // ReLU outputs of the input / skip projections, raw skip sum
     float *h_save, *g_save, *sig_save, *tnh_save;   // per layer (stride act_stride floats): h, gate product, sigmoid, tanh
@@ -67,9 +74,10 @@ struct PersistArgs {
     float rsNL;
     // Two problems in one grid (mg_denoiser_fwd_pair; b_split > 0): utterances [0, b_split) are problem 1 (x_t, out,
     // hvec, dvec; nothing saved), [b_split, B) problem 2 (x_t2, out2, hvec2, dvec2; the SAVE stores, indexed from 0).
-    // Same weights, same conditioner rows (utterance b - b_split of problem 2 uses cond row b - b_split).  post == 0.
+    // Same weights; problem 2 reads its own conditioner cond2 (utterance b - b_split uses row b - b_split; the caller
+    // passes cond again when both phases share it).  post == 0.
     int b_split;
-    const float *x_t2, *hvec2, *dvec2;
+    const float *x_t2, *hvec2, *dvec2, *cond2;
     float *out2;
 };
 
@@ -202,6 +210,22 @@ __device__ __forceinline__ float dp_normal(unsigned long long seed, unsigned lon
 }
 
 #define DP_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// A hand-off wait gave up (lane 0 of the waiting wave): set the workspace's sticky error word and the host-visible one,
+// and make both visible before this workgroup sends anything computed from the halo it never got.
+__device__ __forceinline__ void dp_fail(unsigned *sync, unsigned *host_err, unsigned code)
+{
+    __hip_atomic_store(sync + 1, code, DP_RLX_AGENT);
+    if (host_err) __hip_atomic_store(host_err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+}
+// End of a workgroup: has this launch (or an earlier one on this workspace) failed?  Every workgroup whose tile
+// depends on a dead neighbour's columns received them after that neighbour's dp_fail, so it sees the word set here.
+__device__ __forceinline__ bool dp_failed(unsigned *sync)
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return __hip_atomic_load(sync + 1, DP_RLX_AGENT) != 0u;
+}
 #define DP_STAMP(k) do { if (TIMING && tid == 0) a.dbg[((size_t)tile * (a.NL + 2) + stamp_row) * 12 + (k)] = clock64(); } while (0)
 
 template <int NT, bool VEC4, bool TIMING = false, bool SAVE = false, int NWV = NT / 8>
@@ -247,6 +271,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
     }
     __syncthreads();
     const int tile = min((int)s_tile, n_tiles - 1);
+    const unsigned launch_no = s_launch;   // launches completed on this workspace: hand-off tags and the noise offset
     const int bg = tile / a.tiles_per_b, jt = tile - bg * a.tiles_per_b;   // bg: utterance in the grid
     const bool second = a.b_split > 0 && bg >= a.b_split;                   // wave-uniform (workgroup-uniform)
     const int b = second ? bg - a.b_split : bg;                             // utterance inside its problem
@@ -265,7 +290,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
 
     // ---------------------------------------------------------------- stage the cond tile (once) and the x_t tile
     {
-        const float *cb = a.cond + (size_t)b * RB_C * L;
+        const float *cb = (second ? a.cond2 : a.cond) + (size_t)b * RB_C * L;
         if (VEC4) {
 #pragma unroll
             for (int k = 0; k < 64 * NT / NTHR; ++k) {   // 256 rows x NT/4 float4 (frames l0 .. l0+NT-1)
@@ -350,13 +375,12 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
             for (int j = 0; j < NNB; ++j) save_block(a.x0_save, rbase + 32 * i, j, [&](int r) { return st[i][j][r]; });
     }
     dp_gu64 *const gran = (dp_gu64 *)a.gran;
-    dp_gu32 *const err = (dp_gu32 *)(a.sync + 1);
 
     for (int l = 0; l < a.NL; ++l) {
         const float *lp = a.layers + (size_t)l * a.layer_stride;
         const float *hv = (second ? a.hvec2 : a.hvec) + ((size_t)l * Bp + b) * RB_C;
         const float *dv = (second ? a.dvec2 : a.dvec) + ((size_t)l * Bp + b) * RB_C;
-        const unsigned epoch = a.epoch_base + (unsigned)l + 1u;
+        const unsigned epoch = launch_no * ((unsigned)a.NL + 1u) + (unsigned)l + 1u;   // never repeats on a workspace
         const int par = l & 1;
         stamp_row = l + 1;
         DP_STAMP(0);
@@ -409,7 +433,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
         // ------------------------------------------------------------ hand the edge columns to the neighbours
         // wave 0: my frame l0 -> right halo of tile-1;  wave 1: my frame l0+NT-1 -> left halo of tile+1
         if (w < 2) {
-            const bool go = w == 0 ? has_left : has_right;
+            bool go = w == 0 ? has_left : has_right;
+            if ((a.flags & DP_F_WITHHOLD) && w == 0 && jt == 1) go = false;
             if (go) {
                 const int dst_tile = w == 0 ? tile - 1 : tile + 1;
                 const int col = w == 0 ? 1 : NT;
@@ -442,7 +467,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
             const bool from = w == 0 ? has_left : has_right;
             const int col = w == 0 ? 0 : NT + 1;
             unsigned v[4] = {0u, 0u, 0u, 0u};
-            if (from && s_dead == 0u) {   // after a timeout: keep going (results are garbage), never hang
+            if (from && s_dead == 0u) {   // after a timeout: keep going (the output is poisoned at the end), never hang
                 dp_gu64 *g = gran + (((size_t)par * n_tiles + tile) * 2 + w) * RB_C;
                 unsigned spins = 0;
                 for (;;) {
@@ -454,9 +479,9 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
                         ok &= (unsigned)(x >> 32) == epoch;
                     }
                     if (__all(ok)) break;
-                    if (++spins > DP_SPIN_LIMIT) {   // uniform across the wave
+                    if (++spins > a.spin_limit) {   // uniform across the wave
                         if (lane == 0) {
-                            __hip_atomic_store(err, 1u + (unsigned)l, DP_RLX_AGENT);
+                            dp_fail(a.sync, a.host_err, 1u + (unsigned)l);
                             s_dead = 1u;
                         }
                         break;
@@ -582,11 +607,15 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
         dp_mfma_loop<1, 1, NC, DpIterK1>(o, ap, condT + (32 * nb + c32) * 8 + hh * 4);
         const int f = l0 + 32 * nb + c32;
         const size_t bo = (size_t)b * a.M * L;
+        // a hand-off timed out somewhere in this launch (or an earlier one on this workspace whose error nobody has
+        // cleared): no tile may look like a result
+        const bool bad = dp_failed(a.sync);
+        const float poison = __builtin_nanf("");
         if (!a.post) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = 32 * mb + 8 * (r >> 2) + 4 * hh + (r & 3);
-                if (row < a.M && f < L) x_out[bo + (size_t)row * L + f] = o[0][0][r];
+                if (row < a.M && f < L) x_out[bo + (size_t)row * L + f] = bad ? poison : o[0][0][r];
             }
         } else {
             // p_sample tail (model/diffusion.py:113-129): clamp, posterior mean, + sigma * noise unless t == 0
@@ -594,7 +623,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
             tb = tb < 0 ? 0 : (tb >= a.n_steps ? a.n_steps - 1 : tb);
             const float c1 = a.coef1[tb], c2 = a.coef2[tb];
             const float sg = tb == 0 ? 0.f : __expf(0.5f * a.logvar[tb]);
-            const unsigned long long seed = a.seed, off = s_launch;
+            const unsigned long long seed = a.seed, off = (a.noise_stream << 32) | (unsigned long long)launch_no;
             const int fc = min(f, L - 1);
             float xt[16], nz[16];
 #pragma unroll
@@ -612,7 +641,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
                     float x0 = o[0][0][r];
                     if (a.x0_out) a.x0_out[e] = x0;
                     if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
-                    a.out[e] = fmaf(sg, nz[r], fmaf(c1, x0, c2 * xt[r]));
+                    a.out[e] = bad ? poison : fmaf(sg, nz[r], fmaf(c1, x0, c2 * xt[r]));
                 }
             }
         }

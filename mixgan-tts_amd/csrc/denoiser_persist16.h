@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256, 2) void denoiser_persist16_kernel(PersistArgs 
     }
     __syncthreads();
     const int tile = (int)(s_tile % (unsigned)n_tiles);
+    const unsigned launch_no = s_launch;   // launches completed on this workspace: hand-off tags and the noise offset
     const int b = tile / a.tiles_per_b, jt = tile - b * a.tiles_per_b;
     const int l0 = jt * NT;
     const bool has_left = jt > 0, has_right = jt + 1 < a.tiles_per_b;
@@ -160,7 +161,6 @@ __global__ __launch_bounds__(256, 2) void denoiser_persist16_kernel(PersistArgs 
     }
 
     dp_gu64 *const gran = (dp_gu64 *)a.gran;
-    dp_gu32 *const err = (dp_gu32 *)(a.sync + 1);
     // 16-row block rb (of a 512- or 256-row matrix) at 8-channel group 0: container block rb >> 1, sub-block rb & 1
     auto blk = [&](const float *base, int rb, int Q) {
         return reinterpret_cast<const f32x4 *>(base) + ((size_t)(rb >> 1) * Q + (rb & 1)) * 64 + lane;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void denoiser_persist16_kernel(PersistArgs 
         const float *pp = a.p16layers + (size_t)l * a.p16layer_stride;  // 16-row packs
         const float *hv = a.hvec + ((size_t)l * a.B + b) * RB_C;
         const float *dv = a.dvec + ((size_t)l * a.B + b) * RB_C;
-        const unsigned epoch = a.epoch_base + (unsigned)l + 1u;
+        const unsigned epoch = launch_no * ((unsigned)a.NL + 1u) + (unsigned)l + 1u;
         const int par = l & 1;
 
         // ------------------------------------------------------------ GEMM 1: h = Wc cond + bc + x + (Wd s [+ Wp spk])
@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256, 2) void denoiser_persist16_kernel(PersistArgs 
         __syncthreads();   // interior columns of hT complete
 
         if (w < 2) {   // hand the edge columns to the neighbours
-            const bool go = w == 0 ? has_left : has_right;
+            bool go = w == 0 ? has_left : has_right;
+            if ((a.flags & DP_F_WITHHOLD) && w == 0 && jt == 1) go = false;
             if (go) {
                 const int dst_tile = w == 0 ? tile - 1 : tile + 1;
                 const int col = w == 0 ? 1 : NT;
@@ -244,9 +245,9 @@ __global__ __launch_bounds__(256, 2) void denoiser_persist16_kernel(PersistArgs 
                         ok &= (unsigned)(x >> 32) == epoch;
                     }
                     if (__all(ok)) break;
-                    if (++spins > DP_SPIN_LIMIT) {
+                    if (++spins > a.spin_limit) {
                         if (lane == 0) {
-                            __hip_atomic_store(err, 1u + (unsigned)l, DP_RLX_AGENT);
+                            dp_fail(a.sync, a.host_err, 1u + (unsigned)l);
                             s_dead = 1u;
                         }
                         break;
@@ -324,18 +325,20 @@ __global__ __launch_bounds__(256, 2) void denoiser_persist16_kernel(PersistArgs 
         const f32x4 *const ap[1] = {blk(a.out_w, rb, 32)};
         d16_mfma_loop<1, NC, D16IterK1>(o, ap, condT + c16 * 16 + g * 4);
         const size_t bo = (size_t)b * a.M * L;
+        const bool bad = dp_failed(a.sync);   // a hand-off timed out: no tile of this launch may look like a result
+        const float poison = __builtin_nanf("");
         if (!a.post) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * rb + 4 * g + r;
-                if (row < a.M && fvalid) a.out[bo + (size_t)row * L + f] = o[0][r];
+                if (row < a.M && fvalid) a.out[bo + (size_t)row * L + f] = bad ? poison : o[0][r];
             }
         } else {   // p_sample tail (model/diffusion.py:113-129)
             long tb = (long)a.t[b];
             tb = tb < 0 ? 0 : (tb >= a.n_steps ? a.n_steps - 1 : tb);
             const float c1 = a.coef1[tb], c2 = a.coef2[tb];
             const float sg = tb == 0 ? 0.f : __expf(0.5f * a.logvar[tb]);
-            const unsigned long long seed = a.seed, off = s_launch;
+            const unsigned long long seed = a.seed, off = (a.noise_stream << 32) | (unsigned long long)launch_no;
             const int fc = min(f, L - 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void denoiser_persist16_kernel(PersistArgs 
                     float x0 = o[0][r];
                     if (a.x0_out) a.x0_out[e] = x0;
                     if (a.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
-                    a.out[e] = fmaf(sg, nz, fmaf(c1, x0, c2 * xt));
+                    a.out[e] = bad ? poison : fmaf(sg, nz, fmaf(c1, x0, c2 * xt));
                 }
             }
         }

@@ -1,6 +1,8 @@
 """Denoiser (model/modules.py:382-446): same constructor, state_dict keys and forward
 signature as the reference; the forward is one call into `mg_denoiser_fwd`."""
 import ctypes
+import itertools
+import os
 from collections import OrderedDict
 
 import torch
@@ -9,6 +11,47 @@ from torch import nn
 from . import _lib
 from ._lib import fptr, iptr, check, stream_ptr, DenoiserDims
 from .blocks import ConvNorm, LinearNorm, Mish, DiffusionEmbedding, ResidualBlock
+
+
+# Every workspace instance of the process gets its own number: it is the high word of the in-kernel Philox offset
+# (mg_denoiser_psample's noise_stream), the launch count kept inside the workspace is the low word.  A new shape, a
+# workspace re-allocated after the cache evicted it and a second captured graph therefore never walk the same stream.
+_NOISE_STREAMS = itertools.count(1)
+
+
+def _rank_salt(dev):
+    """Distinct per (rank, device): ranks that seed torch identically must not draw identical in-kernel noise."""
+    rank = 0
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            rank = dist.get_rank()
+        else:
+            rank = int(os.environ.get("RANK", "0"))
+    except (ValueError, RuntimeError):
+        rank = 0
+    z = (rank * 0x9E3779B97F4A7C15 + ((dev.index or 0) + 1) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+    z ^= z >> 31                                             # splitmix-style finaliser
+    z = (z * 0x94D049BB133111EB) & (2 ** 64 - 1)
+    return z ^ (z >> 29)
+
+
+def raise_if_failed(owners=(), sync=False):
+    """The single-launch kernels' failure word (include/mixgan_hip.h, mg_persist_error).  Polling it is a host memory
+    read; sync=True first waits for the current stream, which makes the answer exact for everything launched so far.
+    On a failure the owners' workspaces (whose sticky error words now poison every launch) are dropped and
+    MixganHipError is raised."""
+    if sync:
+        torch.cuda.current_stream().synchronize()
+    code = _lib.lib().mg_persist_error(1)
+    if code:
+        for o in owners:
+            o.drop_workspaces()
+        where = ("forward, layer %d" % (code - 1)) if code < 0x100 else ("backward, layer %d" % (code - 0x100))
+        raise _lib.MixganHipError(
+            "a neighbour hand-off of the single-launch denoiser kernel timed out (%s): another tenant is holding the "
+            "GPU's workgroup slots.  The launch drained and its output is NaN; set MG_DENOISER_PERSIST=0 to use the "
+            "launch-per-layer kernels on a shared GPU." % where)
 
 
 class Denoiser(nn.Module):
@@ -45,10 +88,15 @@ class Denoiser(nn.Module):
         self._bws = OrderedDict()
         self._save_gen = 0
         self._grad_sink = None        # (flat buffer, {id(param): offset}) bound by distributed.GradBucket
+        self._sink_used = False
         # "fp32": exact fp32 MFMA everywhere.  "bf16x3": inference-only forward whose residual-layer
         # GEMMs run as 3-term bf16-split products on the bf16 MFMA (fp32-grade, ~1e-5 relative);
         # grad-enabled forwards always take the fp32 path (the backward consumes fp32 activations).
         self.precision = "fp32"
+        # callable(torch.cuda.Event) | None: called from the backward right after the library call, with an event that
+        # marks the k=3 conv weight / bias gradients of all layers final in the bound gradient buffer (the rest of the
+        # backward is still queued behind it) -- HotPathTrainer starts their all-reduce there
+        self.after_conv3_grads = None
 
     # ------------------------------------------------------------------ packed-weight cache
     def _weight_table(self):
@@ -98,7 +146,18 @@ class Denoiser(nn.Module):
         hipGraph, which must hold the tensor for as long as the graph lives."""
         n = _lib.lib().mg_denoiser_workspace_floats(ctypes.byref(self._dims), B, L, int(save))
         # zero-filled once: the single-launch forward keeps its ticket / launch counters in here and re-arms them itself
-        return torch.zeros(n, device=dev, dtype=torch.float32)
+        ws = torch.zeros(n, device=dev, dtype=torch.float32)
+        ws._mg_noise_stream = next(_NOISE_STREAMS)
+        return ws
+
+    def drop_workspaces(self):
+        """Forget every cached workspace (after a reported kernel failure their sticky error words stay set)."""
+        self._ws.clear()
+        self._bws.clear()
+
+    def check(self, sync=True):
+        """Raise MixganHipError if a single-launch kernel reported a hand-off timeout (see raise_if_failed)."""
+        raise_if_failed((self,), sync)
 
     def _workspace(self, B, L, save, dev):
         """Cached per shape.  The cache only saves re-allocation: whoever needs a workspace to outlive the call (a
@@ -123,6 +182,7 @@ class Denoiser(nn.Module):
         ws: explicit workspace (default: the per-shape cache).  With save=True the workspace that now holds the
         layer activations is left in `self.last_ws` for the caller to keep until its backward."""
         B, M, L = x_t.shape
+        raise_if_failed((self,))      # a failure of earlier work that the host has not noticed yet (free: no sync)
         if packed is None:
             packed = self.packed_weights(with_backward=save)
         if ws is None:
@@ -142,12 +202,14 @@ class Denoiser(nn.Module):
                                          ws.numel(), B, L, mode, stream_ptr()))
         return out
 
-    def run_pair(self, x_a, t_a, x_b, t_b, cond, spk):
-        """Two forwards over the same weights, conditioner and speakers in ONE launch (mg_denoiser_fwd_pair): problem a
-        without saves (the GAN step's D-phase forward), problem b with the activations kept like run(save=True) (its
-        G-phase forward; the workspace is left in `self.last_ws` / returned).  -> (out_a, out_b, ws_b), or None when the
-        single-launch kernel does not take the shape (run them separately then)."""
+    def run_pair(self, x_a, t_a, x_b, t_b, cond, spk, cond_b=None, spk_b=None):
+        """Two forwards over the same weights in ONE launch (mg_denoiser_fwd_pair): problem a without saves (the GAN
+        step's D-phase forward), problem b with the activations kept like run(save=True) (its G-phase forward; the
+        workspace is left in `self.last_ws` / returned).  cond_b / spk_b: problem b's conditioner / speakers when they
+        differ from a's.  -> (out_a, out_b, ws_b), or None when the single-launch kernel does not take the shape (run
+        them separately then)."""
         Bh, M, L = x_a.shape
+        raise_if_failed((self,))
         packed = self.packed_weights(with_backward=True)
         dev = x_a.device
         ws_a = self._workspace(2 * Bh, L, False, dev)
@@ -155,7 +217,9 @@ class Denoiser(nn.Module):
         out_a, out_b = torch.empty_like(x_a), torch.empty_like(x_b)
         rc = _lib.lib().mg_denoiser_fwd_pair(ctypes.byref(self._dims), fptr(packed), fptr(x_a), iptr(t_a, torch.int64),
                                              fptr(x_b), iptr(t_b, torch.int64), fptr(cond),
-                                             fptr(spk, not self.multi_speaker), fptr(out_a), fptr(out_b), fptr(ws_a),
+                                             fptr(spk, not self.multi_speaker), fptr(cond_b, True),
+                                             fptr(spk_b if self.multi_speaker else None, True), fptr(out_a),
+                                             fptr(out_b), fptr(ws_a),
                                              ws_a.numel(), fptr(ws_b), ws_b.numel(), Bh, L, stream_ptr())
         if rc == -2:        # MG_ERR_SHAPE: not a shape of the single-launch kernel
             return None
@@ -170,10 +234,13 @@ class Denoiser(nn.Module):
                  packed=None, ws=None):
         """One reverse step (model/diffusion.py:121-129) as one library call: x_0 = forward(x_t); clamp; posterior mean
         + sigma * noise.  x_t [B,M,L], cond [B,H,L]; coef1 / coef2 / logvar: the diffusion's posterior_mean_coef1 / 2 and
-        posterior_log_variance_clipped buffers.  noise None = drawn in the kernel (Philox keyed by a seed taken once
-        from torch's generator, counter kept on the device: fresh on every call and every graph replay).
+        posterior_log_variance_clipped buffers.  noise None = drawn in the kernel: Philox keyed by a seed taken once
+        from torch's generator (so torch.manual_seed reproduces a run) mixed with the rank and device; the counter is
+        (this workspace's process-wide number, launches on it so far -- kept on the device), fresh on every call, every
+        shape, every re-allocated workspace and every replay of every captured graph.
         Returns x_{t-1} [B,M,L] (a new tensor or `out`, never x_t itself)."""
         B, M, L = x_t.shape
+        raise_if_failed((self,))
         if packed is None:
             packed = self.packed_weights()
         if ws is None:
@@ -181,15 +248,23 @@ class Denoiser(nn.Module):
         if out is None:
             out = torch.empty_like(x_t)
         if getattr(self, "_rng_seed", None) is None:
-            self._rng_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            self._rng_seed = (int(torch.randint(0, 2 ** 62, (1,)).item()) ^ _rank_salt(x_t.device)) & (2 ** 64 - 1)
         mode = 2 if self.precision == "bf16x3" else 0
         if self._packed_key is not None and (self._packed_key[0] & 4) and packed is self._packed:
             mode |= 4
         check(_lib.lib().mg_denoiser_psample(
             ctypes.byref(self._dims), fptr(packed), fptr(x_t), iptr(t, torch.int64), fptr(cond),
             fptr(spk, not self.multi_speaker), fptr(coef1), fptr(coef2), fptr(logvar), coef1.numel(), fptr(noise, True),
-            self._rng_seed, int(bool(clip)), fptr(out), fptr(x0_out, True), fptr(ws), ws.numel(), B, L, mode, stream_ptr()))
+            self._rng_seed, self._noise_stream_of(ws), int(bool(clip)), fptr(out), fptr(x0_out, True), fptr(ws),
+            ws.numel(), B, L, mode, stream_ptr()))
         return out
+
+    @staticmethod
+    def _noise_stream_of(ws):
+        n = getattr(ws, "_mg_noise_stream", None)
+        if n is None:      # a caller-made workspace: number it on first use
+            n = ws._mg_noise_stream = next(_NOISE_STREAMS)
+        return n
 
     def persist_status(self, B, L, ws=None):
         """{ticket, error, launches, done} of the single-launch forward's counters for this shape (synchronises);
@@ -250,6 +325,7 @@ class Denoiser(nn.Module):
         sink = self._grad_sink
         use_sink = (sink is not None and sink[0].device == dev
                     and all(p is None or (p.grad is None and id(p) in sink[1]) for p in table))
+        self._sink_used = use_sink
         def alloc(p, lead=()):
             if p is None:
                 return None
@@ -271,6 +347,7 @@ class Denoiser(nn.Module):
         dev = x_t.device
         d = self._dims
         NL = d.n_layers
+        raise_if_failed((self,))
         packed = self.packed_weights(with_backward=True)
         k = (B, L, dev)
         bws = self._bws.get(k)
@@ -292,8 +369,13 @@ class Denoiser(nn.Module):
         d_x = torch.empty_like(x_t) if want_dx else None
         d_cond = torch.empty_like(cond) if want_dcond else None
         d_spk = torch.empty_like(spk) if (want_dspk and spk is not None) else None
-        check(L_.mg_denoiser_bwd(ctypes.byref(d), fptr(packed), fptr(g_out), fptr(x_t), fptr(cond),
-                                 fptr(spk, not self.multi_speaker), fptr(ws), fptr(bws), bws.numel(), ptrs,
-                                 fptr(d_x, True), fptr(d_cond, True), fptr(d_spk, True), B, L, stream_ptr()))
+        hook = self.after_conv3_grads if self._sink_used else None
+        ev = torch.cuda.Event() if hook is not None else None
+        check(L_.mg_denoiser_bwd_staged(ctypes.byref(d), fptr(packed), fptr(g_out), fptr(x_t), fptr(cond),
+                                        fptr(spk, not self.multi_speaker), fptr(ws), fptr(bws), bws.numel(), ptrs,
+                                        fptr(d_x, True), fptr(d_cond, True), fptr(d_spk, True), B, L,
+                                        ctypes.c_void_p(ev.cuda_event) if ev is not None else None, stream_ptr()))
+        if hook is not None:
+            hook(ev)
         ws._mg_busy = False
         return d_x, d_cond, d_spk, [g for g in grads if g is not None]

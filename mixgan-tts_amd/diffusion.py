@@ -9,7 +9,10 @@ Differences a caller can see (all opt-in or documented in DESIGN.md):
     instead of the reference's T+1 retained tensors (SURVEY.md section 8 a8);
   * `use_graph` (attribute, default False): the inference branch of forward() replays its T-step loop as one
     captured hipGraph;
-  * no tqdm progress bars in the sampling loop (they force a host iteration per step).
+  * no tqdm progress bars in the sampling loop (they force a host iteration per step);
+  * `check_failures` (attribute, default True): `sampling()` waits for its last step and raises MixganHipError if a
+    single-launch kernel reported a hand-off timeout (its output is NaN then; include/mixgan_hip.h, mg_persist_error)
+    -- callers that pipeline further GPU work behind `sampling()` and check `denoise_fn.check()` themselves turn it off.
 """
 import json
 import os
@@ -49,6 +52,7 @@ class GaussianDiffusion(nn.Module):
         # inference through forward(): replay the T-step loop as one captured hipGraph (BASELINE configs[2]);
         # synthesize.py-style callers set `model.diffusion.use_graph = True` once
         self.use_graph = False
+        self.check_failures = True
         self.cond = None
         self.spk_emb = None
 
@@ -135,7 +139,9 @@ class GaussianDiffusion(nn.Module):
         if use_graph and self.noise_fn is None:
             x = self._bml(torch.randn((B, 1, M, L), device=dev) if noise is None else noise)
             x = self._sampling_graph(x, cond, self.spk_emb)
-            return [ops.transpose_bml(x, True, 2, self.spec_min, self.spec_max, _final_keep)]
+            res = [ops.transpose_bml(x, True, 2, self.spec_min, self.spec_max, _final_keep)]
+            self._check_failed()
+            return res
         buf = self._buf()
         den = self.denoise_fn
         packed = den.packed_weights()
@@ -149,7 +155,18 @@ class GaussianDiffusion(nn.Module):
                 xs.append(x)
         outs = xs if keep_trace else [x]
         res = [ops.transpose_bml(a, True, 2, self.spec_min, self.spec_max) for a in outs[:-1]]
-        return res + [ops.transpose_bml(outs[-1], True, 2, self.spec_min, self.spec_max, _final_keep)]
+        res = res + [ops.transpose_bml(outs[-1], True, 2, self.spec_min, self.spec_max, _final_keep)]
+        self._check_failed()
+        return res
+
+    def _check_failed(self):
+        """End of a sampling loop: one stream synchronisation, then the failure word (a host memory read)."""
+        if self.check_failures and not torch.cuda.is_current_stream_capturing():
+            try:
+                self.denoise_fn.check(sync=True)
+            except _lib.MixganHipError:
+                self._graph = None       # the captured graph's own workspace carries the sticky error word
+                raise
 
     def _sampling_graph(self, x_start, cond, spk):
         """The T-step p_sample loop as one hipGraph: captured once per (B, L, T, device) on a side
@@ -217,10 +234,18 @@ class GaussianDiffusion(nn.Module):
             trace.append(ops.transpose_bml(self._bml(x), True))
         return trace
 
-    # HotPathTrainer sets this around its D-phase forward: the next (grad-enabled) forward on the same inputs is launched
-    # together with it (Denoiser.run_pair).  Off by default: it draws that second forward's randomness early.
+    # HotPathTrainer sets this around its D-phase forward: the next (grad-enabled) forward is launched together with it
+    # (Denoiser.run_pair).  Off by default: it draws that second forward's randomness early.  pair_inputs: the
+    # (cond, spk_emb, coarse_mel) that grad-enabled forward will be called with (the reference's two model calls of a
+    # step see different conditioners when the encoder has dropout, train.py:133,153); None = the same as this call's.
     pair_forward = False
+    pair_inputs = None
     _pair_stash = None
+
+    @staticmethod
+    def _pair_key(mel, cond, spk, mel_mask, coarse_mel):
+        return (mel.data_ptr(), mel._version, cond.data_ptr(), cond._version, mel_mask.data_ptr(), tuple(mel.shape),
+                None if coarse_mel is None else coarse_mel.data_ptr(), None if spk is None else spk.data_ptr())
 
     def forward(self, mel, cond, spk_emb, mel_mask, coarse_mel=None, clip_denoised=True):
         """model/diffusion.py:187-226.  mel [B,L,M]|None, cond [B,L,H], mel_mask bool [B,L] True = pad."""
@@ -259,8 +284,7 @@ class GaussianDiffusion(nn.Module):
             x_t_ = ops.diffuse(melc, t_, self._bml(self._randn((B, 1, M, L), dev)), keep, buf)
             x_prev_ = ops.diffuse(melc, (t_ - 1).contiguous(), self._bml(self._randn((B, 1, M, L), dev)), keep, buf)
             return t_, x_t_, x_prev_, self._bml(self._randn((B, 1, M, L), dev))
-        pair_key = (mel.data_ptr(), mel._version, cond.data_ptr(), cond._version, mel_mask.data_ptr(), tuple(mel.shape),
-                    None if coarse_mel is None else coarse_mel.data_ptr(), None if spk is None else spk.data_ptr())
+        pair_key = self._pair_key(mel, cond, spk, mel_mask, coarse_mel)
         stash, self._pair_stash = self._pair_stash, None
         if grad:
             from .autograd import denoise_and_posterior
@@ -290,11 +314,21 @@ class GaussianDiffusion(nn.Module):
             # with (train.py:153), with fresh t / noise.  Draw the second set now (nothing else consumes randomness in
             # between) and run both in one launch; the grad-enabled call that follows picks its half up above.
             draws2 = draw()
-            both = self.denoise_fn.run_pair(x_t_b, t, draws2[1], draws2[0], cond_t, spk)
+            cond_g, spk_g, coarse_g = self.pair_inputs if self.pair_inputs is not None else (cond, spk_emb, coarse_mel)
+            spk_g = spk_g.contiguous() if spk_g is not None else None
+            cond_t2 = spk2 = None
+            if cond_g is not cond:
+                if cond_g.shape != cond.shape:
+                    raise _lib.MixganHipError("pair_inputs: the two phases' conditioners differ in shape")
+                cond_t2 = ops.transpose_bml(cond_g.detach().contiguous(), False)
+            if spk_g is not None and spk is not None and spk_g.data_ptr() != spk.data_ptr():
+                spk2 = spk_g.detach()
+            both = self.denoise_fn.run_pair(x_t_b, t, draws2[1], draws2[0], cond_t, spk, cond_t2, spk2)
             if both is not None:
                 x0 = both[0]
             # (not a single-launch shape: the second forward still uses these draws, so that the random stream is
             # consumed in the same order either way)
+            pair_key = self._pair_key(mel, cond_g, spk_g, mel_mask, coarse_g)
             self._pair_stash = {"key": pair_key, "draws": draws2, "x0": None if both is None else both[1],
                                 "ws": None if both is None else both[2],
                                 "packed": self.denoise_fn._packed, "packed_key": self.denoise_fn._packed_key}

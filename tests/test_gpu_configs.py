@@ -139,3 +139,161 @@ def test_cfg4_long_form_denoiser_and_T1000_chain(mg, manifest, tmp_path):
     gd._graph = None
     noisy = gd.sampling(noise=x_T, keep_trace=False, use_graph=True)[0]
     assert torch.isfinite(noisy).all() and not torch.equal(noisy, eager)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Whole workloads at the per-GPU shard size of BASELINE configs[3] and configs[4]: the
+# components were covered at full size, the workloads only at small size.
+# ------------------------------------------------------------------------------------------------------------------
+def _cfg3_trainer(mg, manifest, stats):
+    args, pre, mc, tr = hot_path_configs("naive", 4, multi_speaker=True, stats_dir=stats)
+    G = mg.GaussianDiffusion(args, pre, mc, tr)
+    D = mg.JCUDiscriminator(pre, mc, tr)
+    load_seeded(G, manifest, "diffusion_naive_ms1", 32)
+    load_seeded(D, manifest, "jcu_ms1", 42)
+    with torch.no_grad():   # the fixture recipe leaves output_projection at its zero init: make the path live
+        G.denoise_fn.output_projection.conv.weight.normal_(0, 0.05, generator=torch.Generator().manual_seed(3))
+    trainer = mg.HotPathTrainer(G.cuda(), D.cuda(), tr, mc)
+    seen = []
+    trainer.grad_hook = lambda name, bucket: seen.append((name, bucket.flat.detach().clone()))
+    return trainer, seen
+
+
+def test_cfg3_training_step_at_the_full_per_gpu_shard(mg, manifest, tmp_path):
+    """BASELINE configs[3]: AISHELL3 multi-speaker GAN step, batch 64 over 8 GPUs = B=8, L=1000 per GPU.  Two
+    HotPathTrainer.step()s at exactly that shard: finite; reproducible given pinned t / noise; and after step 1 the
+    reduced-gradient buckets equal the mean of the buckets of two B=4 half shards (what the 8-GPU all-reduce relies on,
+    SURVEY.md section 8e; train.py:133-184)."""
+    e = golden("elementwise")
+    stats = write_stats(tmp_path, e["spec_min"], e["spec_max"], n_speakers=5)
+    B, L, steps = 8, 1000, 2
+    gen = torch.Generator().manual_seed(83)
+    mel = (torch.rand(B, L, 80, generator=gen) * 13.5 - 11.5).cuda()
+    cond = torch.randn(B, L, 256, generator=gen).cuda()
+    spk = torch.randn(B, 256, generator=gen).cuda()
+    ts = [torch.randint(0, 4, (B,), generator=gen) for _ in range(2 * steps)]
+    noises = [torch.randn(B, 1, 80, L, generator=gen) for _ in range(6 * steps)]
+
+    def run(lo, hi, n_steps):
+        trainer, seen = _cfg3_trainer(mg, manifest, stats)
+        trainer.G.t_fn = Tape([t[lo:hi].numpy() for t in ts])
+        trainer.G.noise_fn = Tape([n[lo:hi].numpy() for n in noises])
+        pad = torch.zeros(hi - lo, L, dtype=torch.bool, device="cuda")
+        outs = [trainer.step(mel[lo:hi].contiguous(), cond[lo:hi].contiguous(), spk[lo:hi].contiguous(), pad)
+                for _ in range(n_steps)]
+        vals = [trainer.log_scalars(o) for o in outs]           # also raises on a hand-off timeout
+        return vals, seen, trainer
+
+    vals, seen, trainer = run(0, B, steps)
+    assert [n for n, _ in seen] == ["D", "G"] * steps
+    for v in vals:
+        assert all(np.isfinite(x) for x in v.values()), v
+    for _, flat in seen:
+        assert torch.isfinite(flat).all()
+    assert all(torch.isfinite(p).all() for p in list(trainer.G.parameters()) + list(trainer.D.parameters()))
+    # reproducible (a few reductions combine partial sums with atomics: to rounding, not bitwise)
+    vals2, seen2, _ = run(0, B, steps)
+    for a, b in zip(vals, vals2):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-5 * max(1.0, abs(a[k])), k
+    for i, ((_, f1), (_, f2)) in enumerate(zip(seen, seen2)):
+        tol = 1e-5 if i < 2 else 2e-3       # step 2 starts from weights that may differ in the last bits
+        assert (f1 - f2).abs().max().item() <= tol * f1.abs().max().item(), i
+    # the two half shards
+    _, h0, _ = run(0, B // 2, 1)
+    _, h1, _ = run(B // 2, B, 1)
+    for i, name in enumerate(("D", "G")):
+        full, avg = seen[i][1], 0.5 * (h0[i][1] + h1[i][1])
+        err = (full - avg).abs().max().item() / full.abs().max().item()
+        assert err <= 3e-4, "%s bucket: full shard vs mean of half shards %.2e" % (name, err)
+
+
+class _FixedEncoder(torch.nn.Module):
+    """Stands in for the linguistic encoder (upstream of the path): hands back a fixed conditioner and frame counts."""
+
+    def __init__(self, cond, mel_lens):
+        super().__init__()
+        self.cond, self.mel_lens = cond, mel_lens
+
+    def forward(self, *args, **kwargs):
+        B, L, _ = self.cond.shape
+        valid = torch.arange(L, device=self.cond.device)[None, :] < self.mel_lens[:, None]     # True = valid here
+        z = torch.zeros(B, 3, device=self.cond.device)
+        return self.cond, None, None, z, z, self.mel_lens, valid, None, None
+
+
+def test_cfg4_shallow_long_form_inference_end_to_end(mg, manifest, tmp_path):
+    """BASELINE configs[4]: 'shallow' inference on L=4000 frames with the f16 MFMA attention path and the T=1000
+    reverse chain, end to end through MixGANTTS.forward (model/mixgantts.py:136-160, model/diffusion.py:194-200):
+    Decoder (L above max_seq_len) -> mel_linear -> PostNet -> diffuse_fn(coarse, T-1) -> 1000 p_sample steps -> denorm
+    * mask.  B=2: graph replay == eager loop bit for bit with sigma = 0 and the same diffuse_fn draw; each utterance
+    alone gives the same mel as inside the batch; finite with the in-kernel noise on; the coarse mel against the oracle
+    (fp32 attention 5e-5, f16 attention 2e-3 of the mel's range)."""
+    from oracle import weights as WR
+    Tn, B, L = 1000, 2, 4000
+    stats = write_stats(tmp_path, np.linspace(-11.5, -9.0, 80), np.linspace(1.0, 2.0, 80))
+    gen = torch.Generator().manual_seed(404)
+    cond = (torch.randn(B, L, 256, generator=gen) * 0.5).cuda()
+    mel_lens = torch.tensor([L, L - 517]).cuda()
+    man = manifest["mixgantts_shallow_ms0"]
+    w = WR.draw(man["seeded"], 61)
+
+    def build(rows):
+        m = mg.MixGANTTS(*hot_path_configs("shallow", Tn, stats_dir=stats),
+                         linguistic_encoder=_FixedEncoder(cond[rows].contiguous(), mel_lens[rows].contiguous()))
+        sd = m.state_dict()
+        for k, a in w.items():
+            if k in sd and tuple(sd[k].shape) == a.shape:       # the T=4 recipe's schedule buffers have another length
+                sd[k] = torch.from_numpy(a)
+        m.load_state_dict(sd)
+        with torch.no_grad():
+            m.diffusion.denoise_fn.output_projection.conv.weight.normal_(0, 0.05, generator=torch.Generator().manual_seed(3))
+        return m.cuda().eval()
+
+    def infer(m, seed=5):
+        n = m.linguistic_encoder.cond.shape[0]
+        z = torch.zeros(n, dtype=torch.long, device="cuda")
+        torch.manual_seed(seed)                                   # diffuse_fn's torch.randn draw
+        with torch.no_grad():
+            out, _, coarse = m(z, torch.ones(n, 5, dtype=torch.long, device="cuda"), torch.full((n,), 5, device="cuda"), 5,
+                               torch.ones(n, 3, dtype=torch.long, device="cuda"), torch.full((n,), 3, device="cuda"), 3)
+        return out[0], coarse
+
+    m = build(slice(0, B))
+    assert m.diffusion.num_timesteps == Tn
+    # ---- coarse mel vs the oracle, utterance 0 (fp32 attention, then the f16 path of this config)
+    Wt = {k: T(a) for k, a in w.items()}
+    pad = torch.arange(L)[None, :] >= mel_lens.cpu()[:, None]
+    with torch.no_grad():
+        ref = R.coarse_mel(Wt, cond[:1].cpu(), pad[:1], max_seq_len=1000)
+        c32 = m.coarse_mel(cond, pad.cuda())
+        m.decoder.set_attention_precision("f16")
+        c16 = m.coarse_mel(cond, pad.cuda())
+    assert_close(c32[:1].cpu(), ref, 5e-5, "coarse mel, L=4000 > max_seq_len, fp32 attention")
+    assert_close(c16[:1].cpu(), ref, 2e-3, "coarse mel, f16 MFMA attention")
+    # ---- the whole inference, sigma = 0: captured graph == eager loop, batch independence
+    sched = m.diffusion.posterior_log_variance_clipped.clone()
+    m.diffusion.posterior_log_variance_clipped.fill_(-1.0e4)
+    eager, coarse_e = infer(m)
+    m.diffusion.use_graph = True
+    graphed, coarse_g = infer(m)
+    assert tuple(eager.shape) == (B, L, 80) and torch.isfinite(eager).all()
+    assert torch.equal(coarse_e, coarse_g) and torch.equal(eager, graphed)
+    assert (eager[1, L - 517:] == 0).all() and eager[1, :L - 517].abs().max() > 0
+    m.diffusion.use_graph = False
+    one = build(slice(1, 2))
+    one.decoder.set_attention_precision("f16")
+    one.diffusion.posterior_log_variance_clipped.fill_(-1.0e4)
+    # the same diffuse_fn noise for utterance 1: draw the batch's tensor and hand its row over
+    torch.manual_seed(5)
+    nz = torch.randn((B, 1, 80, L), device="cuda")
+    one.diffusion.noise_fn = lambda shape: nz[1:2]
+    alone, _ = infer(one)
+    assert_close(alone[0].cpu(), eager[1].cpu(), 1e-5, "utterance 1 alone vs inside the batch")
+    # ---- in-kernel noise on: finite, differs from the sigma = 0 chain, fresh per call
+    m.diffusion.posterior_log_variance_clipped.copy_(sched)
+    m.diffusion.use_graph = True
+    m.diffusion._graph = None
+    n1, _ = infer(m)
+    n2, _ = infer(m)
+    assert torch.isfinite(n1).all() and not torch.equal(n1, eager) and not torch.equal(n1, n2)

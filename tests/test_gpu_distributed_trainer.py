@@ -4,7 +4,11 @@ before clipping.  With t and every noise draw pinned per sample, the reduced gra
 after them must equal a single process stepping on the concatenated batch.  Step 2 is the interesting one: its D
 gradient contains the reference's D-gradient leak (the G-phase backward of step 1 deposits into D's .grad, train.py
 never clears it before the next D phase), which stays local on each rank until the step-2 D all-reduce sums it.
-gloo carries the all-reduce (RCCL needs one GPU per rank; the driver's multi-GPU runs use nccl)."""
+gloo carries the all-reduce here (RCCL needs one GPU per rank; the driver's multi-GPU runs use nccl) -- through the same
+chunked path: the k=3 weight gradients enter the collective behind an event while the backward is still running
+(GradBucket.all_reduce_chunk_async), the rest follows in all_reduce_mean.  A second test runs one trainer step with the
+"nccl" backend (RCCL) on a world of one, collectives forced: the flat bucket, the side stream and the event hand-off are
+legal for RCCL, and the result equals the step without any process group."""
 import os
 import socket
 
@@ -38,7 +42,7 @@ def _data():
     return mel, cond, spk, ts, noises
 
 
-def _run(mg, manifest, stats_dir, lo, hi):
+def _run(mg, manifest, stats_dir, lo, hi, always_exchange=False, chunks=None):
     """STEPS trainer steps on samples [lo, hi); returns reduced gradients per update and the final weights."""
     args, pre, mc, tr = hot_path_configs("naive", 4, multi_speaker=True, stats_dir=stats_dir)
     G = mg.GaussianDiffusion(args, pre, mc, tr)
@@ -52,6 +56,10 @@ def _run(mg, manifest, stats_dir, lo, hi):
     G.t_fn = Tape([t[lo:hi].numpy() for t in ts])
     G.noise_fn = Tape([n[lo:hi].numpy() for n in noises])
     trainer = mg.HotPathTrainer(G, D, tr, mc)
+    trainer.bucketG.always_exchange = trainer.bucketD.always_exchange = always_exchange
+    if chunks is not None:      # count the early chunks that went out
+        inner = trainer.bucketG.all_reduce_chunk_async
+        trainer.bucketG.all_reduce_chunk_async = lambda *a, **k: chunks.append(a[:2]) or inner(*a, **k)
     seen = []
     trainer.grad_hook = lambda name, bucket: seen.append((name, bucket.flat.detach().cpu().clone()))
     pad = torch.zeros(hi - lo, L, dtype=torch.bool, device="cuda")
@@ -74,7 +82,9 @@ def _worker(rank, world, port, stats_dir, q):
         with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "manifest.json")) as f:
             manifest = json.load(f)
         per = B // world
-        seen, weights = _run(mg, manifest, stats_dir, rank * per, (rank + 1) * per)
+        chunks = []
+        seen, weights = _run(mg, manifest, stats_dir, rank * per, (rank + 1) * per, chunks=chunks)
+        assert len(chunks) == STEPS and all(hi - lo > 7_000_000 for lo, hi in chunks), chunks   # one early chunk per G update
         # numpy arrays are pickled by value (shared-memory tensors would need this process to outlive the receive)
         q.put((rank, [(n, f.numpy()) for n, f in seen], {k: v.numpy() for k, v in weights.items()}))
     finally:
@@ -136,3 +146,52 @@ def _update_distance(weights, ref_w, init):
         num += float((d_got - d_ref).pow(2).sum())
         den += float(d_ref.pow(2).sum())
     return num, den
+
+
+def _rccl_worker(port, stats_dir, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)      # "nccl" IS RCCL on ROCm
+    try:
+        import json
+        import mixgan_tts_amd as mg
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "manifest.json")) as f:
+            manifest = json.load(f)
+        assert dist.get_backend() == "nccl"
+        chunks = []
+        seen, weights = _run(mg, manifest, stats_dir, 0, B, always_exchange=True, chunks=chunks)
+        torch.cuda.synchronize()
+        q.put(("ok", len(chunks), [(n, f.numpy()) for n, f in seen], {k: v.numpy() for k, v in weights.items()}))
+    except Exception as exc:      # report instead of hanging the parent on q.get
+        q.put(("error", repr(exc), None, None))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_world_of_one_runs_the_bucketed_exchange(manifest, tmp_path):
+    """init_process_group("nccl") + HotPathTrainer.step x2 with the collectives forced on a world of one: RCCL loads and
+    accepts the flat bucket slices, the side-stream launch behind the backward's event and the stream-level waits; the
+    reduced gradients and the weights equal the same steps without a process group (sum over one rank, divided by 1)."""
+    import mixgan_tts_amd as mg
+    e = golden("elementwise")
+    stats = write_stats(tmp_path, e["spec_min"], e["spec_max"], n_speakers=5)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), stats, q))
+    p.start()
+    status, n_chunks, seen, weights = q.get(timeout=600)
+    p.join(120)
+    assert status == "ok", n_chunks
+    assert p.exitcode == 0
+    assert n_chunks == STEPS
+    ref_seen, ref_w = _run(mg, manifest, stats, 0, B)
+    assert [n for n, _ in seen] == [n for n, _ in ref_seen] == ["D", "G"] * STEPS
+    for i, ((name, flat), (_, ref)) in enumerate(zip(seen, ref_seen)):
+        tol = 2e-5 if i < 2 else 2e-3      # step 2 starts from weights that already differ in the last bits
+        err = (torch.from_numpy(flat) - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
+        assert err <= tol, "update %d (%s): %.2e" % (i, name, err)
+    num, den = _update_distance({k: torch.from_numpy(v) for k, v in weights.items()}, ref_w,
+                                _initial_weights(mg, manifest, stats))
+    assert den > 0 and (num / den) ** 0.5 <= 2e-2

@@ -106,6 +106,129 @@ def test_in_kernel_noise_is_standard_normal_and_fresh(mg, manifest, tmp_path):
     assert abs(torch.corrcoef(torch.stack([za.flatten(), zb.flatten()]))[0, 1].item()) < 0.01   # a fresh stream per call
 
 
+def _corr(a, b):
+    n = min(a.numel(), b.numel())
+    return abs(torch.corrcoef(torch.stack([a.flatten()[:n], b.flatten()[:n]]))[0, 1].item())
+
+
+def test_in_kernel_noise_streams_never_repeat(mg, manifest, tmp_path):
+    """The reference draws fresh torch.randn_like noise in every p_sample (model/diffusion.py:32-35,118).  The in-kernel
+    generator's counter is (workspace number, launches on that workspace): the first launch on ANOTHER workspace -- a new
+    shape, the same shape after the 8-entry cache evicted it, a second captured graph -- must not replay the first
+    launch of the first one (round 2: every workspace restarted at offset 0 under one seed)."""
+    e = golden("elementwise")
+    stats = write_stats(tmp_path, e["spec_min"], e["spec_max"])
+    gd = mg.GaussianDiffusion(*hot_path_configs("naive", 4, stats_dir=stats))
+    load_seeded(gd, manifest, "diffusion_naive_ms0", 31)
+    gd = gd.cuda().eval()
+    den = gd.denoise_fn
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    M = 80
+
+    def problem(B, L):
+        return (torch.randn(B, M, L, device="cuda", generator=gen), torch.full((B,), 3, device="cuda"),
+                torch.randn(B, 256, L, device="cuda", generator=gen))
+
+    def z_of(x, t, cond, **kw):
+        """standardised noise of one p_sample: (x_{t-1} - posterior mean) / sigma"""
+        B, _, L = x.shape
+        mean = gd._p_sample_bml(x, t, cond, None, torch.zeros(B, M, L, device="cuda"))
+        out = gd._p_sample_bml(x, t, cond, None, None, **kw)
+        return (out - mean) / torch.exp(0.5 * gd.posterior_log_variance_clipped[t]).view(B, 1, 1)
+
+    with torch.no_grad():
+        pa, pb = problem(2, 256), problem(2, 320)
+        za1 = z_of(*pa)                       # first launch with in-kernel noise on workspace (2, 256)
+        zb1 = z_of(*pb)                       # ... on workspace (2, 320): same flat element indices for utterance 0
+        n = za1.numel()
+        assert abs(za1.var().item() - 1.0) < 0.03 and abs(zb1.var().item() - 1.0) < 0.03
+        assert _corr(za1, zb1) < 5.0 / n ** 0.5, "two shapes drew the same noise"
+        assert _corr(za1[0], zb1[0]) < 5.0 / (n / 2) ** 0.5
+        for i in range(9):                    # push (2, 256) out of the 8-entry workspace cache
+            z_of(*problem(1, 32 + 16 * i))
+        assert (2, 256, False, pa[0].device) not in den._ws
+        za2 = z_of(*pa)                       # first in-kernel-noise launch on the re-allocated workspace
+        assert _corr(za1, za2) < 5.0 / n ** 0.5, "a re-allocated workspace replayed the old workspace's stream"
+
+        # two captured graphs of the same step, each owning its workspace; replays of one graph; graph vs graph
+        packed = den.packed_weights()
+        x, t, cond = pa
+        mean = gd._p_sample_bml(x, t, cond, None, torch.zeros_like(x))
+        sig = torch.exp(0.5 * gd.posterior_log_variance_clipped[t]).view(2, 1, 1)
+        outs = []
+        for _ in range(2):
+            ws, out = den.new_workspace(2, 256, False, x.device), torch.empty_like(x)
+            gd._p_sample_bml(x, t, cond, None, None, out=out, packed=packed, ws=ws)    # warm-up outside the capture
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                gd._p_sample_bml(x, t, cond, None, None, out=out, packed=packed, ws=ws)
+            reps = []
+            for _ in range(2):
+                graph.replay()
+                reps.append(((out - mean) / sig).clone())
+            outs.append((reps, graph, ws))
+        (g1a, g1b), (g2a, g2b) = outs[0][0], outs[1][0]
+        for u, v, what in ((g1a, g1b, "two replays of one graph"), (g1a, g2a, "first replays of two graphs"),
+                           (g1b, g2b, "second replays of two graphs"), (g1a, za1, "a graph and the eager call")):
+            assert abs(u.var().item() - 1.0) < 0.03
+            assert _corr(u, v) < 5.0 / n ** 0.5, what + " drew the same noise"
+    den.check()
+
+
+@pytest.mark.parametrize("nt", [16, 32, 64])
+def test_handoff_timeout_poisons_the_output_and_raises(mg, manifest, tmp_path, monkeypatch, nt):
+    """A neighbour that never sends its edge column (test hook MG_PERSIST_FLAGS bit 1) with the wait bounded to a few
+    polls: the kernel must drain (not hang), its output must be NaN (not a plausible mel), the failure must reach the
+    host as MixganHipError, and the module must work again afterwards."""
+    monkeypatch.setenv("MG_PERSIST_NT", str(nt))
+    den, W = _den(mg, manifest, tmp_path)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    B, L = 2, 200
+    x = torch.randn(B, 1, 80, L, device="cuda", generator=gen)
+    cond = torch.randn(B, 256, L, device="cuda", generator=gen)
+    t = torch.tensor([5, 900], device="cuda")
+    with torch.no_grad():
+        good = den(x, t, cond, None)
+        den.check()
+        ws = den._workspace(B, L, False, x.device)
+        monkeypatch.setenv("MG_PERSIST_SPIN_LIMIT", "40")
+        monkeypatch.setenv("MG_PERSIST_FLAGS", "3")
+        bad = den(x, t, cond, None)
+        monkeypatch.delenv("MG_PERSIST_SPIN_LIMIT")
+        monkeypatch.delenv("MG_PERSIST_FLAGS")
+        torch.cuda.synchronize()                  # returns: every workgroup exited
+        assert torch.isnan(bad[:, 0, :, :nt]).all(), "the tile that timed out wrote a result"
+        assert not torch.isfinite(bad).all()
+        st = den.persist_status(B, L, ws=ws)
+        assert st["error"] != 0 and st["ticket"] == 0 and st["done"] == 0 and st["launches"] >= 2, st
+        with pytest.raises(mg.MixganHipError, match="hand-off"):
+            den.check()
+        assert mg.lib().mg_persist_error(0) == 0   # reported once
+        assert den._workspace(B, L, False, x.device) is not ws      # the poisoned workspace is gone
+        again = den(x, t, cond, None)
+        den.check()
+        assert torch.equal(again, good)
+
+
+def test_sampling_raises_on_a_handoff_timeout(mg, manifest, tmp_path, monkeypatch):
+    e = golden("elementwise")
+    stats = write_stats(tmp_path, e["spec_min"], e["spec_max"])
+    gd = mg.GaussianDiffusion(*hot_path_configs("naive", 4, stats_dir=stats))
+    load_seeded(gd, manifest, "diffusion_naive_ms0", 31)
+    gd = gd.cuda().eval()
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    gd.cond, gd.spk_emb = torch.randn(2, 256, 150, device="cuda", generator=gen), None
+    ok = gd.sampling(keep_trace=False)[0]
+    assert torch.isfinite(ok).all()
+    monkeypatch.setenv("MG_PERSIST_SPIN_LIMIT", "40")
+    monkeypatch.setenv("MG_PERSIST_FLAGS", "3")
+    with pytest.raises(mg.MixganHipError, match="hand-off"):
+        gd.sampling(keep_trace=False)
+    monkeypatch.delenv("MG_PERSIST_SPIN_LIMIT")
+    monkeypatch.delenv("MG_PERSIST_FLAGS")
+    assert torch.isfinite(gd.sampling(keep_trace=False)[0]).all()
+
+
 @pytest.mark.parametrize("nt", [16, 32, 64, 328])   # 328: 32-frame tiles, 8 waves (one workgroup per CU)
 def test_full_occupancy_handoffs_are_never_stale(mg, manifest, tmp_path, monkeypatch, nt):
     """B=16, L=1000: 512 workgroups, two per CU, every tile waiting on both neighbours in every layer.  The output must be

@@ -174,3 +174,18 @@ def test_get_model_and_checkpoint_round_trip(tmp_path):
     a7 = types.SimpleNamespace(model="shallow", restore_step=7)
     _, _, f7, g7, *_ = mg.get_model(a7, configs, "cpu", train=True)
     assert len(g7.state_dict()["state"]) == 0 and f7.current_step == 7
+
+
+def test_in_kernel_noise_key_differs_per_rank_and_workspaces_are_numbered(monkeypatch):
+    """Ranks that seed torch identically must not draw identical in-kernel noise (the Philox key mixes rank and device
+    in), and every workspace instance gets its own stream number (the high word of the Philox offset)."""
+    from mixgan_tts_amd import denoiser as D
+    dev0, dev1 = torch.device("cuda", 0), torch.device("cuda", 1)
+    salts = set()
+    for rank in range(8):
+        monkeypatch.setenv("RANK", str(rank))
+        salts.add(D._rank_salt(dev0))
+        salts.add(D._rank_salt(dev1))
+    assert len(salts) == 16 and all(0 <= s < 2 ** 64 for s in salts)
+    a, b = next(D._NOISE_STREAMS), next(D._NOISE_STREAMS)
+    assert b == a + 1 and a >= 1
