@@ -43,8 +43,12 @@ def raise_if_failed(owners=(), sync=False):
     MixganHipError is raised."""
     if sync:
         torch.cuda.current_stream().synchronize()
-    code = _lib.lib().mg_persist_error(1)
+    code = _lib.lib().mg_persist_error(0)
     if code:
+        # several workgroups of the failed launch (and launches queued behind it on the poisoned workspace) write the
+        # word: wait for all of them before resetting it, or a straggler would be reported against the next call
+        torch.cuda.synchronize()
+        _lib.lib().mg_persist_error(1)
         for o in owners:
             o.drop_workspaces()
         where = ("forward, layer %d" % (code - 1)) if code < 0x100 else ("backward, layer %d" % (code - 0x100))
@@ -370,7 +374,12 @@ class Denoiser(nn.Module):
         d_cond = torch.empty_like(cond) if want_dcond else None
         d_spk = torch.empty_like(spk) if (want_dspk and spk is not None) else None
         hook = self.after_conv3_grads if self._sink_used else None
-        ev = torch.cuda.Event() if hook is not None else None
+        ev = None
+        if hook is not None:
+            ev = getattr(self, "_conv3_event", None)
+            if ev is None:      # torch creates the hipEvent_t at the first record(): make the handle exist
+                ev = self._conv3_event = torch.cuda.Event()
+                ev.record()
         check(L_.mg_denoiser_bwd_staged(ctypes.byref(d), fptr(packed), fptr(g_out), fptr(x_t), fptr(cond),
                                         fptr(spk, not self.multi_speaker), fptr(ws), fptr(bws), bws.numel(), ptrs,
                                         fptr(d_x, True), fptr(d_cond, True), fptr(d_spk, True), B, L,

@@ -318,11 +318,11 @@ class HotPathTrainer:
         self.sdlD.step()
 
 
-class _DiffusionInputs:
+class _DiffusionInputs(torch.nn.Module):
     """Stands in for model.diffusion while _step_from_model_paired records what MixGANTTS.forward would hand it."""
     model = None
 
-    def __call__(self, mel, cond, spk_emb, mel_mask, coarse_mel=None):
+    def forward(self, mel, cond, spk_emb, mel_mask, coarse_mel=None):
         self.args = (mel, cond, spk_emb, mel_mask, coarse_mel)
         return None, None, None, None, None
 

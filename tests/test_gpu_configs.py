@@ -145,7 +145,7 @@ def test_cfg4_long_form_denoiser_and_T1000_chain(mg, manifest, tmp_path):
 # Whole workloads at the per-GPU shard size of BASELINE configs[3] and configs[4]: the
 # components were covered at full size, the workloads only at small size.
 # ------------------------------------------------------------------------------------------------------------------
-def _cfg3_trainer(mg, manifest, stats):
+def _cfg3_trainer(mg, manifest, stats, reduced_d=None):
     args, pre, mc, tr = hot_path_configs("naive", 4, multi_speaker=True, stats_dir=stats)
     G = mg.GaussianDiffusion(args, pre, mc, tr)
     D = mg.JCUDiscriminator(pre, mc, tr)
@@ -155,7 +155,14 @@ def _cfg3_trainer(mg, manifest, stats):
         G.denoise_fn.output_projection.conv.weight.normal_(0, 0.05, generator=torch.Generator().manual_seed(3))
     trainer = mg.HotPathTrainer(G.cuda(), D.cuda(), tr, mc)
     seen = []
-    trainer.grad_hook = lambda name, bucket: seen.append((name, bucket.flat.detach().clone()))
+
+    def hook(name, bucket):
+        seen.append((name, bucket.flat.detach().clone()))
+        if name == "D" and reduced_d is not None:
+            # what the all-reduce would have left here: the mean over the shards (so that, as on 8 GPUs, every shard's G
+            # phase sees the same updated discriminator)
+            bucket.flat.copy_(reduced_d)
+    trainer.grad_hook = hook
     return trainer, seen
 
 
@@ -174,8 +181,8 @@ def test_cfg3_training_step_at_the_full_per_gpu_shard(mg, manifest, tmp_path):
     ts = [torch.randint(0, 4, (B,), generator=gen) for _ in range(2 * steps)]
     noises = [torch.randn(B, 1, 80, L, generator=gen) for _ in range(6 * steps)]
 
-    def run(lo, hi, n_steps):
-        trainer, seen = _cfg3_trainer(mg, manifest, stats)
+    def run(lo, hi, n_steps, reduced_d=None):
+        trainer, seen = _cfg3_trainer(mg, manifest, stats, reduced_d)
         trainer.G.t_fn = Tape([t[lo:hi].numpy() for t in ts])
         trainer.G.noise_fn = Tape([n[lo:hi].numpy() for n in noises])
         pad = torch.zeros(hi - lo, L, dtype=torch.bool, device="cuda")
@@ -200,8 +207,8 @@ def test_cfg3_training_step_at_the_full_per_gpu_shard(mg, manifest, tmp_path):
         tol = 1e-5 if i < 2 else 2e-3       # step 2 starts from weights that may differ in the last bits
         assert (f1 - f2).abs().max().item() <= tol * f1.abs().max().item(), i
     # the two half shards
-    _, h0, _ = run(0, B // 2, 1)
-    _, h1, _ = run(B // 2, B, 1)
+    _, h0, _ = run(0, B // 2, 1, seen[0][1])
+    _, h1, _ = run(B // 2, B, 1, seen[0][1])
     for i, name in enumerate(("D", "G")):
         full, avg = seen[i][1], 0.5 * (h0[i][1] + h1[i][1])
         err = (full - avg).abs().max().item() / full.abs().max().item()
