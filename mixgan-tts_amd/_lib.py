@@ -48,7 +48,8 @@ class DenoiserDims(ctypes.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, "libmixgan_hip.so")
+    # MG_HIP_LIB: another build of the same library (tools: A/B timing of two builds inside one gpurun call)
+    return os.environ.get("MG_HIP_LIB") or os.path.join(_HERE, "libmixgan_hip.so")
 
 
 def build(force=False):
