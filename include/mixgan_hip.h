@@ -118,6 +118,16 @@ int mg_conv1d_fwd_ex(const float *in, const float *in_vec, const float *packed, 
                      const float *add, float *out, int B, int Ci, int Lin, int Co, int Lout, int K,
                      int stride, int pad, int dil, float in_slope, int act, float act_slope, float alpha,
                      int accumulate, void *stream);
+/* Same, with a split reduction for outputs of few tiles and deep reductions (the JCU discriminator's tail and its data
+ * gradients, model/mixgantts.py:219-248: 512 channels x 5 taps into 128 channels at L/4 frames is 32 output tiles on 256
+ * CUs): when `scratch` is given and the 128 x 128-tile grid would leave most CUs idle, the input-channel chunks of a tile
+ * are dealt to up to 8 workgroups, which leave partial tiles in the scratch; a second, small launch adds them in split
+ * order and applies bias / activation / add.  scratch: fp32, one per stream in flight; 12 Mi floats cover every shape of
+ * the path.  Without scratch, or when a split does not pay, identical to mg_conv1d_fwd_ex. */
+int mg_conv1d_fwd_split(const float *in, const float *in_vec, const float *packed, const float *bias,
+                        const float *add, float *out, int B, int Ci, int Lin, int Co, int Lout, int K, int stride,
+                        int pad, int dil, float in_slope, int act, float act_slope, float alpha, int accumulate,
+                        float *scratch, size_t scratch_floats, void *stream);
 
 /* ------------------------------------------------------------------ diffusion algebra (HBM-bound)
  * Schedule tables are the fp32 buffers of GaussianDiffusion (model/diffusion.py:60-83). */

@@ -10,7 +10,7 @@ _LIB = None
 
 EXPORTS = (
     "mg_version", "mg_error_string",
-    "mg_conv_packed_floats", "mg_conv_pack", "mg_conv_pack_at", "mg_conv1d_fwd", "mg_conv1d_fwd_ex",
+    "mg_conv_packed_floats", "mg_conv_pack", "mg_conv_pack_at", "mg_conv1d_fwd", "mg_conv1d_fwd_ex", "mg_conv1d_fwd_split",
     "mg_upsample_zero_act", "mg_diffuse_trace_bwd", "mg_bgemm", "mg_softmax_rows_fwd", "mg_softmax_rows_bwd", "mg_layernorm_cm_train_fwd",
     "mg_layernorm_cm_bwd", "mg_bn_stats", "mg_bn_act_fwd", "mg_bn_act_bwd_reduce", "mg_bn_act_bwd_apply", "mg_conv_transpose_packed_floats", "mg_conv_transpose_pack", "mg_conv_transpose1d_fwd",
     "mg_conv1d_wgrad_scratch_floats", "mg_conv1d_wgrad", "mg_conv1d_wgrad_strided", "mg_conv1d_wgrad_grouped",
@@ -86,6 +86,7 @@ def _declare(L):
         "mg_conv_pack": (i, [vp, vp, i, i, i, i, vp]),
         "mg_conv1d_fwd": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, f, i, vp]),
         "mg_conv1d_fwd_ex": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, f, i, f, f, i, vp]),
+        "mg_conv1d_fwd_split": (i, [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, f, i, f, f, i, vp, sz, vp]),
         "mg_upsample_zero_act": (i, [vp, vp, i, i, i, i, f, vp]),
         "mg_diffuse_trace_bwd": (i, [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, vp]),
         "mg_bgemm": (i, [vp, vp, vp, i, i, i, i, i] + [lg] * 11 + [f, i, vp]),

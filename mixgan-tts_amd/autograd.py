@@ -133,7 +133,7 @@ class _Conv1dFn(torch.autograd.Function):
         x = x.contiguous()
         Co, Ci, K = weight.shape
         y = ops.conv1d_packed(x, ops.pack_cached(weight), None if bias is None else bias.detach(), Co, K, stride,
-                              padding, act, in_vec=None if in_vec is None else in_vec.detach().contiguous())
+                              padding, act, in_vec=None if in_vec is None else in_vec.detach().contiguous(), split=True)
         ctx.save_for_backward(x, weight, y if act else None, in_vec)
         ctx.cfg = (stride, padding, act, bias is not None)
         return y
@@ -156,7 +156,7 @@ class _Conv1dFn(torch.autograd.Function):
             if stride > 1:
                 src = ops.upsample_zero(dpre, stride, (dpre.shape[2] - 1) * stride + 1)
             dx = ops.conv1d_packed(src, ops.pack_cached(weight, ops.PACK_DGRAD), None, Ci, K, 1, K - 1 - padding,
-                                   Lout=Lin)
+                                   Lout=Lin, split=True)
             if in_vec is not None and need[3]:
                 dvec = ops.rowsum(dx, per_batch=True)
         return dx if need[0] else None, dw, db, dvec, None, None, None

@@ -85,17 +85,26 @@ extern "C" int mg_conv_transpose1d_fwd(const float *in, const float *packed, con
     return conv_launch<EpiBiasAct>(s, in, nullptr, packed, ep, (hipStream_t)stream);
 }
 
+extern "C" int mg_conv1d_fwd_split(const float *in, const float *in_vec, const float *packed, const float *bias,
+                                   const float *add, float *out, int B, int Ci, int Lin, int Co, int Lout, int K,
+                                   int stride, int pad, int dil, float in_slope, int act, float act_slope, float alpha,
+                                   int accumulate, float *scratch, size_t scratch_floats, void *stream)
+{
+    if (!in || !packed || !out) return MG_ERR_ARG;
+    if (act < 0 || act > MG_ACT_LRELU) return MG_ERR_ARG;
+    if (B <= 0 || Ci <= 0 || Co <= 0 || Lin <= 0 || Lout <= 0 || pad < 0 || dil < 1) return MG_ERR_SHAPE;
+    ConvShape s{B, Ci, Lin, Lout, K, stride, pad, Co, 0, 0, dil, in_slope, scratch, scratch ? scratch_floats : 0};
+    EpiBiasAct::Params ep{out, bias, add, alpha, Co, act, accumulate, 0, nullptr, act_slope};
+    return conv_launch<EpiBiasAct>(s, in, in_vec, packed, ep, (hipStream_t)stream);
+}
+
 extern "C" int mg_conv1d_fwd_ex(const float *in, const float *in_vec, const float *packed, const float *bias,
                                 const float *add, float *out, int B, int Ci, int Lin, int Co, int Lout, int K,
                                 int stride, int pad, int dil, float in_slope, int act, float act_slope, float alpha,
                                 int accumulate, void *stream)
 {
-    if (!in || !packed || !out) return MG_ERR_ARG;
-    if (act < 0 || act > MG_ACT_LRELU) return MG_ERR_ARG;
-    if (B <= 0 || Ci <= 0 || Co <= 0 || Lin <= 0 || Lout <= 0 || pad < 0 || dil < 1) return MG_ERR_SHAPE;
-    ConvShape s{B, Ci, Lin, Lout, K, stride, pad, Co, 0, 0, dil, in_slope};
-    EpiBiasAct::Params ep{out, bias, add, alpha, Co, act, accumulate, 0, nullptr, act_slope};
-    return conv_launch<EpiBiasAct>(s, in, in_vec, packed, ep, (hipStream_t)stream);
+    return mg_conv1d_fwd_split(in, in_vec, packed, bias, add, out, B, Ci, Lin, Co, Lout, K, stride, pad, dil, in_slope, act,
+                               act_slope, alpha, accumulate, nullptr, 0, stream);
 }
 
 extern "C" int mg_conv1d_fwd(const float *in, const float *in_vec, const float *packed, const float *bias,

@@ -31,9 +31,17 @@ struct ConvArgs {
     long in_bs;           // batch stride of `in` (floats)
     int in_rs;            // row (channel) stride of `in` (floats), normally Lin
     int B, Ci, CiP, Lin, Lout, pad;
-    int ntiles_per_b, ntiles_total;
+    int ntiles_per_b, ntiles_total, mtiles;
     int dil;              // dilation (<= DILMAX of the instantiation)
     float in_slope;       // leaky-ReLU slope applied to the input samples while staging (1 = identity)
+    // Split reduction (ksplit > 1): workgroup (tile, ks) reduces input-channel chunks [ks * cps, (ks + 1) * cps) and
+    // leaves its accumulators in part[tile][ks]; conv_split_finalize_kernel (a second launch: the kernel boundary is
+    // what makes partial tiles written on one XCD visible on another) adds the ksplit partial tiles in split order
+    // and runs the epilogue.  For convolutions whose output is a few dozen tiles with a reduction thousands deep (the
+    // JCU discriminator's 1/4-rate tail: 512 x 5 taps into 128 channels at L/4 frames, model/mixgantts.py:219-248),
+    // where whole-reduction tiles leave most CUs idle.
+    int ksplit, cps;
+    float *part;          // [tiles][ksplit][WM * NNB * 16][256]
 };
 
 // One element of the packed weight stream (layout above): destination index `idx` inside a [MB][Q][64][4] block
@@ -262,14 +270,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, typename 
     const int wm = MW == 2 ? wave >> 1 : 0, wn = MW == 2 ? wave & 1 : wave;
     const int h = lane >> 5, c32 = lane & 31;
 
-    const int nt = blockIdx.x % a.ntiles_total;
-    const int mt = blockIdx.x / a.ntiles_total;
+    const int ks = a.ksplit > 1 ? (int)(blockIdx.x % (unsigned)a.ksplit) : 0;   // the splits of a tile are neighbours in the grid
+    const int tile_id = a.ksplit > 1 ? (int)(blockIdx.x / (unsigned)a.ksplit) : (int)blockIdx.x;
+    const int nt = tile_id % a.ntiles_total;
+    const int mt = tile_id / a.ntiles_total;
     const int b = nt / a.ntiles_per_b;
     const int l0 = (nt % a.ntiles_per_b) * NT;
     const int mb0 = mt * (MW * WM) + wm * WM;  // first 32-row block of this wave
 
     const int nchunks = a.CiP / CK;
     const int Q = nchunks * QC;
+    const int ch0 = a.ksplit > 1 ? ks * a.cps : 0;                                        // this workgroup's chunks
+    const int ch1 = a.ksplit > 1 ? (ch0 + a.cps < nchunks ? ch0 + a.cps : nchunks) : nchunks;   // (never empty: launcher)
+    const int Qe = ch1 * QC;
 
     // A (weight) stream: one float4 per lane per k-group, sequential in q.
     const f32x4 *ap[WM];
@@ -335,14 +348,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, typename 
 #pragma unroll
     for (int d = 0; d < AD; ++d)
 #pragma unroll
-        for (int i = 0; i < WM; ++i) aq[d][i] = ap[i][(size_t)(d < Q ? d : Q - 1) * 64];
+        for (int i = 0; i < WM; ++i) aq[d][i] = ap[i][(size_t)(ch0 * QC + d < Qe ? ch0 * QC + d : Qe - 1) * 64];
 
 #pragma unroll
-    for (int k = 0; k < NLD; ++k) load_elem(0, k);
-    store_stage(0, 0);
+    for (int k = 0; k < NLD; ++k) load_elem(ch0, k);
+    store_stage(0, ch0);
     __syncthreads();
 
-    int q = 0;
+    int q = ch0 * QC;
     const int boff = (wn * 32 * NNB + c32) * STRIDE + h * TW;
     auto read_b = [&](const float *L, int gi, float (&bv)[4][NNB]) {
         const int tap = gi / (CK / 8), g = gi % (CK / 8);
@@ -352,14 +365,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, typename 
             for (int j = 0; j < NNB; ++j)
                 bv[e][j] = L[boff + (2 * (g * 4 + e)) * TW + (DILMAX > 1 ? tap * a.dil : tap) + 32 * j * STRIDE];
     };
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const float *L = lds[ch & 1];
-        const int chn = ch + 1 < nchunks ? ch + 1 : ch;   // last chunk: harmless reload of itself
+    for (int ch = ch0; ch < ch1; ++ch) {
+        const float *L = lds[(ch - ch0) & 1];
+        const int chn = ch + 1 < ch1 ? ch + 1 : ch;   // last chunk: harmless reload of itself
         float bc[4][NNB], bn[4][NNB];
         read_b(L, 0, bc);
 #pragma unroll
         for (int gi = 0; gi < QC; ++gi) {
-            const int qn = q + AD < Q ? q + AD : Q - 1;
+            const int qn = q + AD < Qe ? q + AD : Qe - 1;
 #pragma unroll
             for (int i = 0; i < WM; ++i) aq[AD][i] = ap[i][(size_t)qn * 64];
 #pragma unroll
@@ -384,11 +397,60 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a, typename 
                 for (int j = 0; j < NNB; ++j) bc[e][j] = bn[e][j];
             ++q;
         }
-        if (ch + 1 < nchunks) store_stage((ch + 1) & 1, ch + 1);
+        if (ch + 1 < ch1) store_stage((ch + 1 - ch0) & 1, ch + 1);
         __syncthreads();
     }
 
+    if (a.ksplit > 1) {   // the partial tile of this split: conv_split_finalize_kernel adds them up and runs the epilogue
+        float *pp = a.part + ((size_t)tile_id * a.ksplit + ks) * (size_t)(WM * NNB * 16 * 256) + tid;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < NNB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pp[((i * NNB + j) * 16 + r) * 256] = acc[i][j][r];
+        return;
+    }
     Epi::template run<WM, NNB>(ep, acc, b, (mt * MW + wm) * (32 * WM), l0 + wn * 32 * NNB, lane, a.Lout);
+}
+
+// One wave per 32 x 32 block of a split convolution's output: sum the ksplit partial blocks in split order (four
+// splits' loads in flight at a time), then the epilogue of the unsplit kernel on that block.
+template <int MW, int WM, int NNB, class Epi>
+__global__ __launch_bounds__(256) void conv_split_finalize_kernel(ConvArgs a, typename Epi::Params ep)
+{
+    constexpr int NW = 4 / MW, NT = NW * 32 * NNB, BLK = WM * NNB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const long unit = (long)blockIdx.x * 4 + (tid >> 6);   // (tile, wave of the conv workgroup, block of that wave)
+    const long n_units = (long)a.ntiles_total * a.mtiles * 4 * BLK;
+    if (unit >= n_units) return;
+    const int blk = (int)(unit % BLK), wave = (int)((unit / BLK) % 4);
+    const int tile_id = (int)(unit / (4 * BLK));
+    const int i = blk / NNB, j = blk - i * NNB;
+    const int wm = MW == 2 ? wave >> 1 : 0, wn = MW == 2 ? wave & 1 : wave;
+    const int nt = tile_id % a.ntiles_total, mt = tile_id / a.ntiles_total;
+    const int b = nt / a.ntiles_per_b, l0 = (nt % a.ntiles_per_b) * NT;
+    const size_t split_stride = (size_t)BLK * 16 * 256;
+    const float *pt = a.part + (size_t)tile_id * a.ksplit * split_stride + (size_t)blk * 16 * 256 + wave * 64 + lane;
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    int sp = 0;
+    for (; sp + 4 <= a.ksplit; sp += 4) {
+        float v[4][16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[u][r] = pt[(size_t)(sp + u) * split_stride + r * 256];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] += v[u][r];
+    }
+    for (; sp < a.ksplit; ++sp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += pt[(size_t)sp * split_stride + r * 256];
+    Epi::template run<1, 1>(ep, acc, b, (mt * MW + wm) * (32 * WM) + 32 * i, l0 + wn * 32 * NNB + 32 * j, lane, a.Lout);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -400,11 +462,15 @@ struct ConvShape {
     int in_rs;   // 0 -> Lin
     int dil = 1;
     float in_slope = 1.f;
+    float *scratch = nullptr;      // split-reduction scratch (mg_conv1d_fwd_split): the partial tiles
+    size_t scratch_floats = 0;
 };
+
+
 
 template <int KW, int STRIDE, int CK, int DILMAX, int MW, int WM, int NNB, class Epi>
 static int conv_launch_t(const ConvShape &s, const float *in, const float *in_vec, const float *wp,
-                         const typename Epi::Params &ep, hipStream_t st)
+                         const typename Epi::Params &ep, hipStream_t st, int ksplit = 1)
 {
     ConvArgs a;
     a.in = in;
@@ -423,9 +489,29 @@ static int conv_launch_t(const ConvShape &s, const float *in, const float *in_ve
     a.ntiles_per_b = mg_cdiv(s.Lout, (4 / MW) * 32 * NNB);
     a.ntiles_total = a.ntiles_per_b * s.B;
     const int mtiles = mg_cdiv(s.Mrows, 32 * MW * WM);
-    dim3 grid((unsigned)(a.ntiles_total * mtiles));
+    a.mtiles = mtiles;
+    a.ksplit = 1;
+    a.cps = 0;
+    a.part = nullptr;
+    if (ksplit > 1) {
+        const int nchunks = a.CiP / CK;
+        const long tiles = (long)a.ntiles_total * mtiles;
+        a.cps = mg_cdiv(nchunks, ksplit);
+        ksplit = mg_cdiv(nchunks, a.cps);   // no empty split
+        const size_t need = (size_t)tiles * ksplit * (WM * NNB * 16 * 256);
+        if (ksplit > 1 && s.scratch && need <= s.scratch_floats) {
+            a.ksplit = ksplit;
+            a.part = s.scratch;
+        }
+    }
+    dim3 grid((unsigned)(a.ntiles_total * mtiles * a.ksplit));
     hipLaunchKernelGGL((conv_mfma_kernel<KW, STRIDE, CK, DILMAX, MW, WM, NNB, Epi>), grid, dim3(256), 0, st, a, ep);
     MG_LAUNCH_CHECK();
+    if (a.ksplit > 1) {
+        const long n_units = (long)a.ntiles_total * mtiles * 4 * WM * NNB;
+        hipLaunchKernelGGL((conv_split_finalize_kernel<MW, WM, NNB, Epi>), dim3((unsigned)((n_units + 3) / 4)), dim3(256), 0, st, a, ep);
+        MG_LAUNCH_CHECK();
+    }
     return MG_OK;
 }
 
@@ -453,6 +539,18 @@ static int conv_launch_k(const ConvShape &s, const float *in, const float *in_ve
         return conv_launch_t<KW, STRIDE, CK, DILMAX, 1, 1, 1, Epi>(s, in, in_vec, wp, ep, st);
     }
     int wm = must_wm1 ? 1 : 2, nnb = 2;
+    // Few tiles, deep reduction, scratch given: keep the large tile (16 MFMAs per k-group and wave instead of 4) and
+    // split the reduction so that about two workgroups land on every CU; each split keeps >= 2 chunks.
+    if (s.scratch && wgs(wm, nnb) < 256) {
+        const int nchunks = mg_round_up(s.Ci, CK) / CK;
+        int ksplit = (int)((384 + wgs(wm, nnb) - 1) / wgs(wm, nnb));
+        if (ksplit > nchunks / 4) ksplit = nchunks / 4;   // >= 4 chunks per split: the pipeline fill is paid per split
+        if (ksplit > 8) ksplit = 8;
+        if (ksplit >= 2) {
+            if (wm == 2) return conv_launch_t<KW, STRIDE, CK, DILMAX, 2, 2, 2, Epi>(s, in, in_vec, wp, ep, st, ksplit);
+            return conv_launch_t<KW, STRIDE, CK, DILMAX, 2, 1, 2, Epi>(s, in, in_vec, wp, ep, st, ksplit);
+        }
+    }
     if (wgs(wm, nnb) < 512) nnb = 1;
     if (wgs(wm, nnb) < 512 && wm == 2 && can_wm1) wm = 1;
     if (wm == 2)

@@ -1,6 +1,7 @@
 """Thin tensor-level wrappers over the C ABI (include/mixgan_hip.h).  Forward only here;
 differentiable entry points live next to the modules that own the parameters."""
 import ctypes
+import os
 
 import torch
 
@@ -69,19 +70,38 @@ def conv_transpose1d_packed(x, packed, bias, Co, u, in_slope=1.0, alpha=1.0):
     return out
 
 
+_SPLIT_SCRATCH = {}
+SPLIT_SCRATCH_FLOATS = 12 << 20
+
+
+def split_scratch(dev):
+    """The split-reduction scratch of mg_conv1d_fwd_split for the current stream.  One per (device, stream): launches
+    on one stream are ordered, launches on different streams must not share partial tiles."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _SPLIT_SCRATCH.get(key)
+    if buf is None:
+        buf = _SPLIT_SCRATCH[key] = torch.empty(SPLIT_SCRATCH_FLOATS, device=dev, dtype=torch.float32)
+    return buf
+
+
 def conv1d_packed(x, packed, bias, Co, K, stride=1, padding=0, act=None, alpha=1.0, add=None, in_vec=None,
-                  out=None, accumulate=False, Lout=None, dilation=1, in_slope=1.0, act_slope=0.0):
+                  out=None, accumulate=False, Lout=None, dilation=1, in_slope=1.0, act_slope=0.0, split=False):
     """act: None | "relu" | "lrelu" (0.2) | "tanh" | "lrelu_s" (slope act_slope); in_slope: leaky ReLU
-    applied to the input while staging (1 = identity)."""
+    applied to the input while staging (1 = identity).  split=True: let the library split a deep reduction over
+    workgroups when the output is only a few tiles (mg_conv1d_fwd_split; same result up to summation order)."""
     L = _lib.lib()
     B, Ci, Lin = x.shape
     if Lout is None:
         Lout = (Lin + 2 * padding - dilation * (K - 1) - 1) // stride + 1
     if out is None:
         out = torch.empty(B, Co, Lout, device=x.device, dtype=torch.float32)
-    check(L.mg_conv1d_fwd_ex(fptr(x), fptr(in_vec, True), fptr(packed), fptr(bias, True), fptr(add, True), fptr(out),
-                             B, Ci, Lin, Co, Lout, K, stride, padding, dilation, float(in_slope), ACT[act],
-                             float(act_slope), float(alpha), int(accumulate), stream_ptr()))
+    scratch = None
+    if split and os.environ.get("MG_CONV_SPLIT", "1") != "0" and not torch.cuda.is_current_stream_capturing():
+        scratch = split_scratch(x.device)
+    check(L.mg_conv1d_fwd_split(fptr(x), fptr(in_vec, True), fptr(packed), fptr(bias, True), fptr(add, True), fptr(out),
+                                B, Ci, Lin, Co, Lout, K, stride, padding, dilation, float(in_slope), ACT[act],
+                                float(act_slope), float(alpha), int(accumulate), fptr(scratch, True),
+                                0 if scratch is None else scratch.numel(), stream_ptr()))
     return out
 
 

@@ -14,6 +14,7 @@ def run():
     c, u = D(x1, x2, None, t)
     (c[-1].sum() + u[-1].sum()).backward()
 for _ in range(3): run()
+print("scratch in use:", len(mg.ops._SPLIT_SCRATCH))
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
