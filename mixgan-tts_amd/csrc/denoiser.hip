@@ -14,6 +14,7 @@
 #include "pointwise_fused.h"
 #include "denoiser_persist.h"
 #include "denoiser_persist16.h"
+#include "denoiser_team16.h"
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
@@ -678,6 +679,14 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
     }
     if (nt == 16 && mg_cdiv(L, 16) > 128) nt = 32;
     if (nt != 32) wide32 = false;
+    // ... and when even the 16-frame tiles number no more than a quarter of the CUs (one utterance of up to 1024 frames,
+    // the configs[0] shape B=4, L<=256): four workgroups per tile, each owning 64 channels (denoiser_team16.h).  The
+    // whole grid must be co-resident, one workgroup per CU.  MG_PERSIST_TEAM=0 keeps one workgroup per tile.
+    bool team = false;
+    if (nt == 16 && !save && w.team != 0) {
+        const char *te = std::getenv("MG_PERSIST_TEAM");
+        team = (long)mg_cdiv(L, 16) * B * DT_TEAM <= mg_device_cus() && !(te && te[0] == '0');
+    }
     const int tiles_per_b = mg_cdiv(L, nt);
     // a quarter of the chip's workgroup slots (one per CU for the 8-wave forms, two for the 4-wave ones)
     const int chain_cap = (nt == 64 || wide32) ? mg_device_cus() / 4 : mg_device_cus() / 2;
@@ -724,6 +733,7 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
         a.noise_stream = post ? post->noise_stream : 0ull;
         a.x0_out = post ? post->x0_out : nullptr;
         a.gran = reinterpret_cast<dp_u64 *>(ws + w.gran);
+        a.team = team ? reinterpret_cast<dp_u64 *>(ws + w.team) : nullptr;
         a.sync = reinterpret_cast<unsigned *>(ws + w.sync);
         a.host_err = mg_host_err_device_ptr();
         a.spin_limit = mg_persist_spin_limit();
@@ -753,7 +763,11 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
         dim3 grid((unsigned)(tiles_per_b * B));
         prof_mark(st, 0);
 #define MG_DP_LAUNCH(NT, V, T, S) hipLaunchKernelGGL((denoiser_persist_kernel<NT, V, T, S>), grid, dim3(NT * 8), 0, st, a)
-        if (nt == 16) {
+        if (nt == 16 && team) {
+            const dim3 tgrid((unsigned)(tiles_per_b * B * DT_TEAM));
+            if (vec4) hipLaunchKernelGGL(denoiser_team16_kernel<true>, tgrid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(denoiser_team16_kernel<false>, tgrid, dim3(256), 0, st, a);
+        } else if (nt == 16) {
             if (vec4) hipLaunchKernelGGL(denoiser_persist16_kernel<true>, grid, dim3(256), 0, st, a);
             else hipLaunchKernelGGL(denoiser_persist16_kernel<false>, grid, dim3(256), 0, st, a);
         } else if (nt == 64) {
@@ -972,6 +986,7 @@ extern "C" int mg_denoiser_fwd_pair(const mg_denoiser_dims *d, const float *pack
     a.seed = a.noise_stream = 0ull;
     a.x0_out = nullptr;
     a.gran = reinterpret_cast<dp_u64 *>(wsA + wA.gran);
+    a.team = nullptr;
     a.sync = reinterpret_cast<unsigned *>(wsA + wA.sync);
     a.host_err = mg_host_err_device_ptr();
     a.spin_limit = mg_persist_spin_limit();

@@ -149,6 +149,7 @@ struct DenWs {
     // single-launch forward (denoiser_persist.h): 64 floats of counters (must be ZERO when the workspace is first used;
     // the kernel re-arms them itself) and the halo hand-off granules [2][tiles][2][C] x 8 bytes
     size_t sync, gran;
+    size_t team;   // denoiser_team16.h: gather buffers of the four-workgroup teams (small launches only; zero at first use)
 };
 
 // 32-frame tiles of the single-launch forward
@@ -184,6 +185,8 @@ static inline DenWs den_ws(const mg_denoiser_dims *d, int B, int L, int save)
     w.conds = take(act);  // frame-major bf16 hi/lo planes of the conditioner (split-precision path)
     w.sync = take(64);
     w.gran = take(2 * den_persist_tiles(B, L) * 2 * C * 2);
+    // [2 parities][tiles][256][18 + 16] granules when the launch is small enough for the team kernel to be considered
+    w.team = take(den_persist_tiles(B, L) <= 128 && C == 256 ? 2 * den_persist_tiles(B, L) * 256 * (18 + 16) * 2 : 0);
     w.total = p;
     return w;
 }

@@ -60,6 +60,7 @@ struct PersistArgs {
     unsigned long long noise_stream;      // unique per workspace instance (host-assigned)
     float *x0_out;                        // optional [B, M, L]: the pre-clamp x_0 when post != 0
     dp_u64 *gran;                         // [2 parity][tiles][2 sides][256] {tag << 32 | float bits}
+    dp_u64 *team;                         // denoiser_team16.h: the teams' gather buffers (same granules), or NULL
     unsigned *sync;                       // [0] / [16] tickets, [1] error (sticky), [2] launches completed, [3] workgroups done;
                                           // zero once at allocation: the last workgroup out re-arms [0], [16] and [3]
     unsigned *host_err;                   // pinned host word (or NULL): receives the error code at system scope
