@@ -30,6 +30,51 @@ struct D16IterAll3 {   // k=3 conv, all taps: (chunk, tap) = (it / 3, it % 3)
     static __device__ __forceinline__ int tap(int it) { return it - 3 * (it / 3); }
 };
 
+// k loop for the teams' one- or two-block wave tiles.  A wave here issues 4 or 8 MFMAs per 16-channel step -- 128 / 256
+// cycles -- so the two-steps-ahead weight prefetch of d16_mfma_loop (sized for four blocks per wave) covers a fraction of
+// an L2 round trip, and with one wave per SIMD nothing else hides it: weights run DIST = 6 steps ahead in a ring of 8,
+// and the first DIST steps are requested by the caller BEFORE it waits for the exchange in front of the GEMM
+// (d16_preload), so the phase opens with its operands in flight.
+template <int NRB, class IT, int DIST = 6>
+__device__ __forceinline__ void d16_preload(f32x4 (&ring)[8][NRB], const f32x4 *const (&ap)[NRB])
+{
+    auto qstep = [](int t) { return 2 * ((IT::chunk(t >> 1) * IT::KW + IT::tap(t >> 1)) * 2 + (t & 1)); };
+#pragma unroll
+    for (int s = 0; s < DIST; ++s)
+#pragma unroll
+        for (int i = 0; i < NRB; ++i) ring[s][i] = ap[i][(size_t)qstep(s) * 64];
+}
+
+template <int NRB, int NTC, class IT, int DIST = 6>
+__device__ __forceinline__ void d16_mfma_loop_deep(f32x4 (&acc)[NRB], const f32x4 *const (&ap)[NRB], const float *__restrict__ tile,
+                                                   f32x4 (&ring)[8][NRB])
+{
+    constexpr int RS = 8, NS = IT::N * 2;   // steps of 16 channels
+    static_assert(NS % RS == 0 && DIST < RS - 1, "whole rings; a slot is rewritten only after its MFMAs");
+    auto qstep = [](int t) { return 2 * ((IT::chunk(t >> 1) * IT::KW + IT::tap(t >> 1)) * 2 + (t & 1)); };   // 8-channel groups
+    auto boff = [](int t) { return ((IT::chunk(t >> 1) * 2 + (t & 1)) * NTC + IT::tap(t >> 1)) * 16; };
+    f32x4 bb[2];
+    bb[0] = *reinterpret_cast<const f32x4 *>(tile + boff(0));
+#pragma unroll 1
+    for (int t0 = 0; t0 < NS; t0 += RS) {
+#pragma unroll
+        for (int u = 0; u < RS; ++u) {
+            const int t = t0 + u;
+            const int ta = t + DIST < NS ? t + DIST : NS - 1, tb = t + 1 < NS ? t + 1 : NS - 1;   // last steps: harmless reloads
+#pragma unroll
+            for (int i = 0; i < NRB; ++i) ring[(u + DIST) % RS][i] = ap[i][(size_t)qstep(ta) * 64];
+            bb[(u + 1) & 1] = *reinterpret_cast<const f32x4 *>(tile + boff(tb));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < NRB; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u][i][e], bb[u & 1][e], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // Gather NCOL columns x 256 channels of tagged granules into a k-interleaved16 LDS tile (column c of the buffer ->
 // column c of the tile).  Columns `skip_lo` / `skip_hi` (the halo columns of an utterance's first / last tile) are not
 // waited for and read as zero.  Returns false after a timeout (the caller marks the launch failed).
@@ -151,12 +196,13 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
             hT[d16_at<NH>(row, c)] = (row < a.M && l0 + c < L) ? v : 0.f;
         }
     }
-    f32x4 X[1], S[1];   // residual stream and skip sum of this wave's 16 channels
+    f32x4 XS[2];   // [0] residual stream, [1] skip sum of this wave's 16 channels
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        X[0][r] = a.in_b[row_of(r)];
-        S[0][r] = 0.f;
+        XS[0][r] = a.in_b[row_of(r)];
+        XS[1][r] = 0.f;
     }
+    f32x4 ringA[8][1], ringB[8][2];   // weight rings: GEMM 1 / skip projection, and GEMM 2 / GEMM 3
     __syncthreads();
     {   // input projection + ReLU (model/modules.py:430-431): K = 96 -> 6 steps of 16 channels
         const f32x4 *wi = reinterpret_cast<const f32x4 *>(a.in_w);   // 12 8-channel groups per 32-row block
@@ -165,10 +211,10 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
             const f32x4 bv = *reinterpret_cast<const f32x4 *>(hT + (s * NH + c16) * 16 + g * 4);
             const f32x4 av = wi[((size_t)(cb >> 1) * 12 + 2 * s + (cb & 1)) * 64 + lane];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) X[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], X[0], 0, 0, 0);
+            for (int e = 0; e < 4; ++e) XS[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], XS[0], 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) X[0][r] = fmaxf(X[0][r], 0.f);
+        for (int r = 0; r < 4; ++r) XS[0][r] = fmaxf(XS[0][r], 0.f);
     }
     __syncthreads();   // x_t has been read out of hT: the first gather may overwrite it
 
@@ -180,6 +226,10 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
         return reinterpret_cast<const f32x4 *>(base) + ((size_t)(rb >> 1) * Q + (rb & 1)) * 64 + lane;
     };
     auto tagged = [](unsigned epoch, float v) { return ((dp_u64)epoch << 32) | (dp_u64)__float_as_uint(v); };
+    {   // the first layer's GEMM 1 weights
+        const f32x4 *const ap0[1] = {blk(a.p16layers + a.p_wc, cb, 32)};
+        d16_preload<1, D16IterK1>(ringA, ap0);
+    }
     // after a timeout: keep going without waiting (the output is poisoned at the end), never hang
     auto failed = [&](unsigned code) {   // called by every lane of the wave whose wait gave up
         if (lane == 0) {
@@ -199,11 +249,15 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
         // ------------------------------------------------------------ GEMM 1: h = Wc cond + bc + x + (Wd s [+ Wp spk])
         f32x4 acc1[1];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc1[0][r] = X[0][r] + (lp[a.l_bc + row_of(r)] + hv[row_of(r)]);
+        for (int r = 0; r < 4; ++r) acc1[0][r] = XS[0][r] + (lp[a.l_bc + row_of(r)] + hv[row_of(r)]);
         {
             const f32x4 *const ap[1] = {blk(pp + a.p_wc, cb, 32)};
-            d16_mfma_loop<1, NC, D16IterK1>(acc1, ap, condT + c16 * 16 + g * 4);
+            d16_mfma_loop_deep<1, NC, D16IterK1>(acc1, ap, condT + c16 * 16 + g * 4, ringA);   // preloaded a phase ago
         }
+        // GEMM 2's first weights: requested now, needed behind the h exchange
+        const int c32 = cb >> 1, half = cb & 1;   // GATE16 packs: per 32 channels, blocks {gate lo, gate hi, filter lo, filter hi}
+        const f32x4 *const ap2[2] = {blk(pp + a.p_w3, 4 * c32 + half, 96), blk(pp + a.p_w3, 4 * c32 + 2 + half, 96)};
+        d16_preload<2, D16IterAll3>(ringB, ap2);
         // GEMM 2's accumulators start at the conv bias (the loads fly during the exchange): [0] gate rows, [1] filter rows
         f32x4 acc2[2];
 #pragma unroll
@@ -234,11 +288,7 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
         __syncthreads();   // hT complete
 
         // ------------------------------------------------------------ GEMM 2 (all three taps); gate
-        {
-            const int c32 = cb >> 1, half = cb & 1;   // GATE16 packs: per 32 channels, blocks {gate lo, gate hi, filter lo, filter hi}
-            const f32x4 *const ap[2] = {blk(pp + a.p_w3, 4 * c32 + half, 96), blk(pp + a.p_w3, 4 * c32 + 2 + half, 96)};
-            d16_mfma_loop<2, NH, D16IterAll3>(acc2, ap, hT + c16 * 16 + g * 4);
-        }
+        d16_mfma_loop_deep<2, NH, D16IterAll3>(acc2, ap2, hT + c16 * 16 + g * 4, ringB);
         {
             dp_gu64 *mine = Gbuf + (size_t)par * g_par + (size_t)tile * RB_C * NG;
 #pragma unroll
@@ -247,11 +297,20 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
                 __hip_atomic_store(mine + (size_t)row_of(r) * NG + c16, tagged(epoch, gv), DP_RLX_AGENT);
             }
         }
-        // GEMM 3's accumulators start as its addends: x + bo + Wd s and skip + bo (model/blocks.py:1166,1174-1176)
+        // GEMM 3's accumulators start as its addends: x + bo + Wd s and skip + bo (model/blocks.py:1166,1174-1176);
+        // XS[0] = x rows, XS[1] = skip rows of this wave's channels: one loop, the g fragments read once for both
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            X[0][r] += lp[a.l_bo + row_of(r)] + dv[row_of(r)];
-            S[0][r] += lp[a.l_bo + RB_C + row_of(r)];
+            XS[0][r] += lp[a.l_bo + row_of(r)] + dv[row_of(r)];
+            XS[1][r] += lp[a.l_bo + RB_C + row_of(r)];
+        }
+        // the first weights of GEMM 3 and of the next layer's GEMM 1 (or of the skip projection): behind the g exchange
+        const f32x4 *const ap3[2] = {blk(pp + a.p_wo, cb, 32), blk(pp + a.p_wo, 16 + cb, 32)};
+        d16_preload<2, D16IterK1>(ringB, ap3);
+        {
+            const f32x4 *const apn[1] = {l + 1 < a.NL ? blk(a.p16layers + (size_t)(l + 1) * a.p16layer_stride + a.p_wc, cb, 32)
+                                                       : blk(a.skip_w, cb, 32)};
+            d16_preload<1, D16IterK1>(ringA, apn);
         }
         if (s_dead == 0u) {
             if (!dt_gather<NG, NG>(Gbuf + (size_t)par * g_par + (size_t)tile * RB_C * NG, gT, epoch, tid, -1, -1, a.spin_limit))
@@ -260,14 +319,9 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
         __syncthreads();   // gT complete (and every wave is done with hT: the next layer's gather may overwrite it)
 
         // ------------------------------------------------------------ GEMM 3: x rows, skip rows
-        {
-            const f32x4 *const apx[1] = {blk(pp + a.p_wo, cb, 32)};
-            const f32x4 *const aps[1] = {blk(pp + a.p_wo, 16 + cb, 32)};
-            d16_mfma_loop<1, NG, D16IterK1>(X, apx, gT + c16 * 16 + g * 4);
-            d16_mfma_loop<1, NG, D16IterK1>(S, aps, gT + c16 * 16 + g * 4);
-        }
+        d16_mfma_loop_deep<2, NG, D16IterK1>(XS, ap3, gT + c16 * 16 + g * 4, ringB);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) X[0][r] *= 0.70710678118654752440f;
+        for (int r = 0; r < 4; ++r) XS[0][r] *= 0.70710678118654752440f;
         // (the next write into gT is the next layer's g gather, behind that layer's hT barrier: every wave has left
         // this GEMM 3 by then)
     }
@@ -279,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
         dp_gu64 *mine = Gbuf + (size_t)parT * g_par + (size_t)tile * RB_C * NG;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            __hip_atomic_store(mine + (size_t)row_of(r) * NG + c16, tagged(epochT, S[0][r] * a.rsNL), DP_RLX_AGENT);
+            __hip_atomic_store(mine + (size_t)row_of(r) * NG + c16, tagged(epochT, XS[1][r] * a.rsNL), DP_RLX_AGENT);
     }
     __syncthreads();   // last GEMM 3 done reading gT
     if (s_dead == 0u) {
@@ -292,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[0][r] = a.skip_b[row_of(r)];
         const f32x4 *const ap[1] = {blk(a.skip_w, cb, 32)};
-        d16_mfma_loop<1, NG, D16IterK1>(acc, ap, gT + c16 * 16 + g * 4);
+        d16_mfma_loop_deep<1, NG, D16IterK1>(acc, ap, gT + c16 * 16 + g * 4, ringA);   // preloaded behind the last layer's g exchange
         dp_gu64 *mine = Hbuf + (size_t)parT * h_par + (size_t)tile * RB_C * NH;   // y -> the h buffer, columns 1..16
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -314,7 +368,8 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
             o[0][r] = row < a.M ? a.out_b[row] : 0.f;
         }
         const f32x4 *const ap[1] = {blk(a.out_w, rb, 32)};
-        d16_mfma_loop<1, NH, D16IterK1>(o, ap, hT + (1 + c16) * 16 + g * 4);
+        d16_preload<1, D16IterK1>(ringA, ap);
+        d16_mfma_loop_deep<1, NH, D16IterK1>(o, ap, hT + (1 + c16) * 16 + g * 4, ringA);
         const size_t bo = (size_t)b * a.M * L;
         const bool bad = dp_failed(a.sync);   // a hand-off timed out: no tile of this launch may look like a result
         const float poison = __builtin_nanf("");
