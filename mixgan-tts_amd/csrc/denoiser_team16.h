@@ -24,11 +24,8 @@
 
 #define DT_TEAM 4
 
-struct D16IterAll3 {   // k=3 conv, all taps: (chunk, tap) = (it / 3, it % 3)
-    static constexpr int N = 24, KW = 3;
-    static __device__ __forceinline__ int chunk(int it) { return it / 3; }
-    static __device__ __forceinline__ int tap(int it) { return it - 3 * (it / 3); }
-};
+// (GEMM 2 walks its reduction in the order of the wider kernels -- centre tap of every chunk, then taps 0 and 2 -- so that
+// an utterance computed by teams is bit-identical to the same utterance inside a batch that runs on 32- or 64-frame tiles.)
 
 // k loop for the teams' one- or two-block wave tiles.  A wave here issues 4 or 8 MFMAs per 16-channel step -- 128 / 256
 // cycles -- so the two-steps-ahead weight prefetch of d16_mfma_loop (sized for four blocks per wave) covers a fraction of
@@ -257,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
         // GEMM 2's first weights: requested now, needed behind the h exchange
         const int c32 = cb >> 1, half = cb & 1;   // GATE16 packs: per 32 channels, blocks {gate lo, gate hi, filter lo, filter hi}
         const f32x4 *const ap2[2] = {blk(pp + a.p_w3, 4 * c32 + half, 96), blk(pp + a.p_w3, 4 * c32 + 2 + half, 96)};
-        d16_preload<2, D16IterAll3>(ringB, ap2);
+        d16_preload<2, DpIterCentre>(ringB, ap2);
         // GEMM 2's accumulators start at the conv bias (the loads fly during the exchange): [0] gate rows, [1] filter rows
         f32x4 acc2[2];
 #pragma unroll
@@ -288,7 +285,9 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
         __syncthreads();   // hT complete
 
         // ------------------------------------------------------------ GEMM 2 (all three taps); gate
-        d16_mfma_loop_deep<2, NH, D16IterAll3>(acc2, ap2, hT + c16 * 16 + g * 4, ringB);
+        d16_mfma_loop_deep<2, NH, DpIterCentre>(acc2, ap2, hT + c16 * 16 + g * 4, ringB);
+        d16_preload<2, DpIterOuter>(ringB, ap2);
+        d16_mfma_loop_deep<2, NH, DpIterOuter>(acc2, ap2, hT + c16 * 16 + g * 4, ringB);
         {
             dp_gu64 *mine = Gbuf + (size_t)par * g_par + (size_t)tile * RB_C * NG;
 #pragma unroll

@@ -392,4 +392,11 @@ def test_team_kernel_one_utterance(mg, manifest, tmp_path, monkeypatch, ms):
         for i in range(B4):
             one = den(x4[i:i + 1], t4[i:i + 1], c4[i:i + 1].contiguous(), None if s4 is None else s4[i:i + 1])
             assert torch.equal(one[0], batch[i]), "utterance %d alone differs from the batch" % i
+        # ... and the teams reduce in the order of the wider kernels: the utterance inside a batch of 64-frame tiles
+        xb = torch.cat([x, torch.randn(15, 1, 80, L, device="cuda", generator=gen)])
+        cb = torch.cat([cond, torch.randn(15, 256, L, device="cuda", generator=gen)])
+        sb = None if spk is None else torch.cat([spk, torch.randn(15, 256, device="cuda", generator=gen)])
+        tb = torch.cat([t, torch.randint(0, 1000, (15,), device="cuda", generator=gen)])
+        big = den(xb, tb, cb, sb)
+        assert torch.equal(big[0], out[0]), "team kernel vs the same utterance in a B=16 batch (64-frame tiles)"
     den.check()
