@@ -123,6 +123,87 @@ def weighted_means(terms):
     return _WeightedMeansFn.apply(tuple(spec), *xs, *ys)
 
 
+class _RangeMeansFn(torch.autograd.Function):
+    """weighted_means over BATCH RANGES of whole feature maps: term k reads rows [a_lo, a_hi) of tensor `ti` (mode 0:
+    mean (x - c)^2; mode 1: mean |x[a] - x[b]| against rows [b_lo, b_lo + a_hi - a_lo) of the same tensor, gradient to
+    the a-range only).  The trainer runs D(fake) and D(real) as one pass over 2B items; slicing the maps apart for the
+    losses made autograd rebuild every map's gradient from two zero-padded halves (a fill, a copy and an add per half
+    and map: ~55 launches per step).  Here the maps go in whole, and the backward is one zero-fill of one flat buffer
+    plus one launch that writes every term's gradient into its range."""
+
+    @staticmethod
+    def forward(ctx, spec, *tensors):
+        nt = len(spec)
+        if nt < 1 or nt > _lib.MG_LOSS_MAX_TERMS:
+            raise ValueError("1..%d terms per call" % _lib.MG_LOSS_MAX_TERMS)
+        xs = [t.contiguous() for t in tensors]
+        terms = (_lib.LossTerm * nt)()
+        for k, (ti, mode, c, w, grp, a_lo, a_hi, b_lo) in enumerate(spec):
+            x = xs[ti]
+            per = x[0].numel()
+            n = (a_hi - a_lo) * per
+            if not (0 <= a_lo < a_hi <= x.shape[0]) or (mode == 1 and not (0 <= b_lo and b_lo + a_hi - a_lo <= x.shape[0])):
+                raise ValueError("term %d: batch range outside the tensor" % k)
+            base = fptr(x).value
+            terms[k] = _lib.LossTerm(base + 4 * a_lo * per, (base + 4 * b_lo * per) if mode == 1 else None, None, n,
+                                     float(c), float(w), int(mode), int(grp))
+        dev = xs[0].device
+        out = torch.empty(1 + _lib.MG_LOSS_GROUPS + nt, device=dev, dtype=torch.float32)
+        check(_lib.lib().mg_multi_loss_fwd(terms, nt, fptr(_multi_scratch(dev)), fptr(out), stream_ptr()))
+        ctx.spec = spec
+        ctx.save_for_backward(*xs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        spec, nt = ctx.spec, len(ctx.spec)
+        xs = ctx.saved_tensors
+        need = [ctx.needs_input_grad[1 + i] for i in range(len(xs))]
+        sizes = [x.numel() if nd else 0 for x, nd in zip(xs, need)]
+        flat = torch.zeros(sum(sizes), device=xs[0].device, dtype=torch.float32)      # rows no term writes: zero
+        grads, at = [], 0
+        for x, nd, n in zip(xs, need, sizes):
+            grads.append(flat[at:at + n].view_as(x) if nd else None)
+            at += n
+        terms = (_lib.LossTerm * nt)()
+        for k, (ti, mode, c, w, grp, a_lo, a_hi, b_lo) in enumerate(spec):
+            x = xs[ti]
+            per = x[0].numel()
+            base = fptr(x).value
+            da = (fptr(grads[ti]).value + 4 * a_lo * per) if grads[ti] is not None else None
+            terms[k] = _lib.LossTerm(base + 4 * a_lo * per, (base + 4 * b_lo * per) if mode == 1 else None, da,
+                                     (a_hi - a_lo) * per, float(c), float(w), int(mode), int(grp))
+        check(_lib.lib().mg_multi_loss_bwd(terms, nt, fptr(g[:1].contiguous()), stream_ptr()))
+        return (None, *grads)
+
+
+def _range_means(spec, tensors):
+    """spec entries (tensor index, mode, c, weight, group, a_lo, a_hi, b_lo); no two terms may write the same rows."""
+    return _RangeMeansFn.apply(tuple(spec), *tensors)
+
+
+def d_loss_total_2b(logit_cond, logit_uncond, B):
+    """d_loss_total on the last maps of ONE discriminator pass over [fake (rows 0..B-1); real (rows B..2B-1)]."""
+    out = _range_means([(0, 0, 1.0, 0.5, 0, B, 2 * B, 0), (1, 0, 1.0, 0.5, 0, B, 2 * B, 0),
+                        (0, 0, 0.0, 0.5, 1, 0, B, 0), (1, 0, 0.0, 0.5, 1, 0, B, 0)], [logit_cond, logit_uncond])
+    return out[0], out[1], out[2]
+
+
+def g_adv_fm_total_2b(cond_maps, uncond_maps, B, lambda_fm, n_layers=5):
+    """g_adv_fm_total on the maps of ONE discriminator pass over [fake; real]: LSGAN on the fake rows of the last maps,
+    feature matching |fake - real| on the others (gradient to the fake rows only, as model/loss.py:221-227 with the real
+    maps as targets)."""
+    w = lambda_fm * (4.0 / (n_layers + 1)) * 0.5
+    nm = len(cond_maps)
+    tensors = list(cond_maps) + list(uncond_maps)
+    spec = [(nm - 1, 0, 1.0, 0.5, 0, 0, B, 0), (2 * nm - 1, 0, 1.0, 0.5, 0, 0, B, 0)]
+    for j in range(nm - 1):
+        spec.append((j, 1, 0.0, w, 1, 0, B, B))
+        spec.append((nm + j, 1, 0.0, w, 1, 0, B, B))
+    out = _range_means(spec, tensors)
+    return out[0], out[1], out[2]
+
+
 def d_loss_total(r_logit_cond, r_logit_uncond, f_logit_cond, f_logit_uncond):
     """d_real + d_fake of get_lsgan_losses_fn()'s d_loss_fn (model/loss.py:12-30, train.py:142-143) as one fused sum.
     Returns (total, d_real, d_fake); differentiate total."""

@@ -124,19 +124,25 @@ class HotPathTrainer:
         the discriminator has no batch-coupled op, so the feature maps are the same as from two calls, and every
         conv of its 1/4-rate tail sees twice the frames per launch (at B=8 those launches fill a quarter of the
         GPU).  Returns (fake_cond, fake_uncond, real_cond, real_uncond) lists of feature maps."""
+        cond_maps, uncond_maps, B = self._d_both(x_ts, x_fake, x_real, spk, t)
+        halves = lambda maps, k: [m[k * B:(k + 1) * B] for m in maps]  # noqa: E731
+        return halves(cond_maps, 0), halves(uncond_maps, 0), halves(cond_maps, 1), halves(uncond_maps, 1)
+
+    def _d_both(self, x_ts, x_fake, x_real, spk, t):
+        """The one discriminator pass over [fake; real]: whole feature maps (rows 0..B-1 fake, B..2B-1 real) and B."""
         B = x_ts.shape[0]
         both = lambda a, b: None if a is None else torch.cat([a, b], 0)  # noqa: E731
         cond_maps, uncond_maps = self.D(both(x_ts, x_ts), both(x_fake, x_real), both(spk, spk), both(t, t))
-        halves = lambda maps, k: [m[k * B:(k + 1) * B] for m in maps]  # noqa: E731
-        return halves(cond_maps, 0), halves(uncond_maps, 0), halves(cond_maps, 1), halves(uncond_maps, 1)
+        return cond_maps, uncond_maps, B
 
     # ------------------------------------------------------------------ the two phases on given generator outputs
     def _d_loss(self, x_ts, x_prevs, x_prev_preds, spk, t):
         """train.py:135-144 / evaluate.py:80-88: everything the generator produced is detached."""
         det = lambda a: None if a is None else a.detach()  # noqa: E731
+        if self.fused_losses:      # the maps go into the loss whole: no slicing for autograd to undo
+            cm, um, B = self._d_both(det(x_ts), det(x_prev_preds), det(x_prevs), det(spk), t)
+            return losses.d_loss_total_2b(cm[-1], um[-1], B)[0]
         f_c, f_u, r_c, r_u = self._d_fake_and_real(det(x_ts), det(x_prev_preds), det(x_prevs), det(spk), t)
-        if self.fused_losses:
-            return losses.d_loss_total(r_c[-1], r_u[-1], f_c[-1], f_u[-1])[0]
         d_real, d_fake = self.d_loss_fn(r_c[-1], r_u[-1], f_c[-1], f_u[-1])
         return d_real + d_fake
 
@@ -144,13 +150,14 @@ class HotPathTrainer:
         """train.py:156-182 with model/loss.py:153-167,196-199: adv + mel L1 (+ postnet L1 in shallow) + lambda_fm * FM
         (+ the caller's upstream terms).  Returns (g_loss, dict of the parts)."""
         G = self.G
-        f_c, f_u, r_c, r_u = self._d_fake_and_real(x_ts, x_prev_preds, x_prevs, spk, t)
         target = coarse_mel.detach() if G.model == "shallow" else mel
         mel_loss = losses.get_mel_loss(G.denorm_spec(x0), target, mel_pad_mask)
         if self.fused_losses:
-            adv_fm, adv, fm = losses.g_adv_fm_total(r_c, r_u, f_c, f_u, self.lambda_fm, self.n_layers)
+            cm, um, B = self._d_both(x_ts, x_prev_preds, x_prevs, spk, t)
+            adv_fm, adv, fm = losses.g_adv_fm_total_2b(cm, um, B, self.lambda_fm, self.n_layers)
             g_loss = adv_fm + mel_loss
         else:
+            f_c, f_u, r_c, r_u = self._d_fake_and_real(x_ts, x_prev_preds, x_prevs, spk, t)
             adv = self.g_loss_fn(f_c[-1], f_u[-1])
             fm = self.lambda_fm * losses.get_fm_loss(r_c, r_u, f_c, f_u, self.n_layers)
             g_loss = adv + mel_loss + fm

@@ -59,6 +59,39 @@ def test_losses_golden(mg):
     assert all(m.grad is None for m in fm_["rc"][:-1] + fm_["ru"][:-1]), "real maps are targets of the FM term: no gradient"
     again = mg.losses.g_adv_fm_total(fm_["rc"], fm_["ru"], fm_["fc"], fm_["fu"], 10.0)[0]
     assert torch.equal(again, g_tot), "fixed summation order"
+    # ... and on the WHOLE maps of one discriminator pass over [fake; real] (what the trainer feeds them): same scalars,
+    # the fake rows' gradients as above, zero (G phase) / the real-logit gradients (D phase) on the real rows
+    Bf = maps["fc"][0].shape[0]
+    whole = {k: [torch.cat([f, r]).cuda().requires_grad_() for f, r in zip(maps["f" + k], maps["r" + k])] for k in ("c", "u")}
+    d2, d2r, d2f = mg.losses.d_loss_total_2b(whole["c"][-1], whole["u"][-1], Bf)
+    g2, adv3, fm3 = mg.losses.g_adv_fm_total_2b(whole["c"], whole["u"], Bf, 10.0)
+    for a, ref in ((d2, d_tot), (d2r, d_r), (d2f, d_f), (g2, g_tot), (adv3, adv2), (fm3, fm2)):
+        assert abs(a.item() - ref.item()) <= 2e-6 * max(1.0, abs(ref.item()))
+    g2.backward()
+    for k in ("c", "u"):
+        for i in range(5):
+            assert_close(whole[k][i].grad[:Bf].cpu(), cm["f" + k][i].grad if i < 4 else _adv_only(cm, k), 1e-6, "2B fake rows %s%d" % (k, i))
+            assert float(whole[k][i].grad[Bf:].abs().sum()) == 0.0, "real rows are targets"
+    for k in ("c", "u"):
+        for m in whole[k]:
+            m.grad = None
+    d2 = mg.losses.d_loss_total_2b(whole["c"][-1], whole["u"][-1], Bf)[0]
+    d2.backward()
+    dr = {k: maps[k][-1].clone().requires_grad_() for k in ("fc", "fu", "rc", "ru")}
+    sum(R.d_loss(dr["rc"], dr["ru"], dr["fc"], dr["fu"])).backward()
+    for k in ("c", "u"):
+        assert_close(whole[k][-1].grad[:Bf].cpu(), dr["f" + k].grad, 1e-6, "D phase, fake logits")
+        assert_close(whole[k][-1].grad[Bf:].cpu(), dr["r" + k].grad, 1e-6, "D phase, real logits")
+        assert all(m.grad is None for m in whole[k][:-1])
+
+
+def _adv_only(cm, k):
+    """Gradient of the last (logit) map from the combined oracle loss of test_losses_golden: r + f + adv + 10 fm -- the
+    2B generator loss holds only adv; recompute that part."""
+    x = cm["f" + k][4].detach().clone().requires_grad_()
+    other = cm["f" + ("u" if k == "c" else "c")][4].detach()
+    (R.g_loss(x, other) if k == "c" else R.g_loss(other, x)).backward()
+    return x.grad
 
 
 def _setup(mg, manifest, tmp_path, B=3, L=40):
