@@ -80,7 +80,15 @@ class FlatAdam(torch.optim.Adam):
     train.py:81-83 become two HIP launches (ops.grad_norm, ops.adam_flat) at 32 bytes of HBM traffic per parameter,
     instead of a norm, a scale and ~10 multi-tensor launches.  Same update rule, same `state_dict()` layout (per
     parameter `step`, `exp_avg`, `exp_avg_sq` -- here views of the flat moments), same `param_groups` (lr schedulers
-    work unchanged).  Build it after the module is on its device; `.to()` afterwards would undo the aliasing."""
+    work unchanged).  Build it after the module is on its device; `.to()` afterwards would undo the aliasing.
+
+    One deliberate difference from torch.optim.Adam: every parameter of the bucket is stepped on every call, with a
+    zero gradient where autograd produced none (GradBucket.gather zero-fills those slices so that all ranks reduce the
+    same buffer and cannot drift apart).  A stock Adam skips a parameter whose .grad is None -- its moments and step
+    count stand still -- whereas here such a parameter's moments decay and it keeps moving along its first moment, and
+    `state_dict()` reports the shared step count for it.  Every parameter of the hot path receives a gradient in every
+    step of train.py:131-184 (the denoiser's speaker projections only in multi-speaker models, where they exist), so the
+    two rules coincide on this path; a caller that steps conditionally-unused parameters through this class should know."""
 
     def __init__(self, bucket, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, param_order=None):
         """param_order: the parameter list a stock optimizer would have been built over (e.g. `model.parameters()`,
