@@ -682,10 +682,16 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
     // ... and when even the 16-frame tiles number no more than a quarter of the CUs (one utterance of up to 1024 frames,
     // the configs[0] shape B=4, L<=256): four workgroups per tile, each owning 64 channels (denoiser_team16.h).  The
     // whole grid must be co-resident, one workgroup per CU.  MG_PERSIST_TEAM=0 keeps one workgroup per tile.
-    bool team = false;
+    // Teams of 4 while tiles x 4 <= CUs, else of 2 while tiles x 2 <= CUs.  MG_PERSIST_TEAM=0 / 2 / 4: none / pin a size.
+    int team = 0;
     if (nt == 16 && !save && w.team != 0) {
         const char *te = std::getenv("MG_PERSIST_TEAM");
-        team = (long)mg_cdiv(L, 16) * B * DT_TEAM <= mg_device_cus() && !(te && te[0] == '0');
+        const long tiles16 = (long)mg_cdiv(L, 16) * B;
+        const int pin = te ? std::atoi(te) : -1;
+        if (pin != 0) {
+            if (tiles16 * 4 <= mg_device_cus() && pin != 2) team = 4;
+            else if (tiles16 * 2 <= mg_device_cus() && pin != 4) team = 2;
+        }
     }
     const int tiles_per_b = mg_cdiv(L, nt);
     // a quarter of the chip's workgroup slots (one per CU for the 8-wave forms, two for the 4-wave ones)
@@ -763,10 +769,14 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
         dim3 grid((unsigned)(tiles_per_b * B));
         prof_mark(st, 0);
 #define MG_DP_LAUNCH(NT, V, T, S) hipLaunchKernelGGL((denoiser_persist_kernel<NT, V, T, S>), grid, dim3(NT * 8), 0, st, a)
-        if (nt == 16 && team) {
-            const dim3 tgrid((unsigned)(tiles_per_b * B * DT_TEAM));
-            if (vec4) hipLaunchKernelGGL(denoiser_team16_kernel<true>, tgrid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL(denoiser_team16_kernel<false>, tgrid, dim3(256), 0, st, a);
+        if (nt == 16 && team == 4) {
+            const dim3 tgrid((unsigned)(tiles_per_b * B * 4));
+            if (vec4) hipLaunchKernelGGL((denoiser_team16_kernel<true, 4>), tgrid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((denoiser_team16_kernel<false, 4>), tgrid, dim3(256), 0, st, a);
+        } else if (nt == 16 && team == 2) {
+            const dim3 tgrid((unsigned)(tiles_per_b * B * 2));
+            if (vec4) hipLaunchKernelGGL((denoiser_team16_kernel<true, 2>), tgrid, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((denoiser_team16_kernel<false, 2>), tgrid, dim3(512), 0, st, a);
         } else if (nt == 16) {
             if (vec4) hipLaunchKernelGGL(denoiser_persist16_kernel<true>, grid, dim3(256), 0, st, a);
             else hipLaunchKernelGGL(denoiser_persist16_kernel<false>, grid, dim3(256), 0, st, a);

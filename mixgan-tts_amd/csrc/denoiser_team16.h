@@ -22,7 +22,8 @@
 #pragma once
 #include "denoiser_persist16.h"
 
-#define DT_TEAM 4
+// Team sizes: 4 (64 channels and 4 waves per workgroup) while tiles x 4 <= CUs, else 2 (128 channels, 8 waves) while
+// tiles x 2 <= CUs -- two utterances of 1000 frames, one of 2000.  (Teams of 8 were measured slower than 4.)
 
 // (GEMM 2 walks its reduction in the order of the wider kernels -- centre tap of every chunk, then taps 0 and 2 -- so that
 // an utterance computed by teams is bit-identical to the same utterance inside a batch that runs on 32- or 64-frame tiles.)
@@ -75,16 +76,17 @@ __device__ __forceinline__ void d16_mfma_loop_deep(f32x4 (&acc)[NRB], const f32x
 // Gather NCOL columns x 256 channels of tagged granules into a k-interleaved16 LDS tile (column c of the buffer ->
 // column c of the tile).  Columns `skip_lo` / `skip_hi` (the halo columns of an utterance's first / last tile) are not
 // waited for and read as zero.  Returns false after a timeout (the caller marks the launch failed).
-template <int NCOL, int NTC>
+template <int NCOL, int NTC, int NTHR>
 __device__ __forceinline__ bool dt_gather(const dp_gu64 *buf, float *T, unsigned epoch, int tid, int skip_lo, int skip_hi,
                                           unsigned spin_limit)
 {
-    constexpr int PER = NCOL;   // 256 * NCOL granules over 256 threads
+    constexpr int PER = NCOL * 256 / NTHR;   // 256 * NCOL granules over the workgroup's threads
+    static_assert(PER <= 32 && (NCOL * 256) % NTHR == 0, "one bit per granule");
     unsigned vals[PER];
     unsigned have = 0;          // bit k: granule k of this thread has arrived (or is not waited for)
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int col = (tid + 256 * k) % NCOL;
+        const int col = (tid + NTHR * k) % NCOL;
         if (col == skip_lo || col == skip_hi) have |= 1u << k;
     }
     unsigned spins = 0;
@@ -93,7 +95,7 @@ __device__ __forceinline__ bool dt_gather(const dp_gu64 *buf, float *T, unsigned
         dp_u64 x[PER];
 #pragma unroll
         for (int k = 0; k < PER; ++k)   // only what is still missing: all loads of a round in flight together
-            if (!((have >> k) & 1u)) x[k] = __hip_atomic_load(buf + tid + 256 * k, DP_RLX_AGENT);
+            if (!((have >> k) & 1u)) x[k] = __hip_atomic_load(buf + tid + NTHR * k, DP_RLX_AGENT);
 #pragma unroll
         for (int k = 0; k < PER; ++k)
             if (!((have >> k) & 1u) && (unsigned)(x[k] >> 32) == epoch) {
@@ -109,7 +111,7 @@ __device__ __forceinline__ bool dt_gather(const dp_gu64 *buf, float *T, unsigned
     }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int idx = tid + 256 * k;
+        const int idx = tid + NTHR * k;
         const int row = idx / NCOL, col = idx - row * NCOL;
         const bool real = col != skip_lo && col != skip_hi && ((have >> k) & 1u);
         T[d16_at<NTC>(row, col)] = real ? __uint_as_float(vals[k]) : 0.f;
@@ -117,9 +119,11 @@ __device__ __forceinline__ bool dt_gather(const dp_gu64 *buf, float *T, unsigned
     return good;
 }
 
-template <bool VEC4>
-__global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
+template <bool VEC4, int TEAM>
+__global__ __launch_bounds__(1024 / TEAM, 2) void denoiser_team16_kernel(PersistArgs a)
 {
+    static_assert(TEAM == 2 || TEAM == 4, "128 or 64 channels per workgroup");
+    constexpr int NWV = 16 / TEAM, NTHR = 64 * NWV;   // one 16-row block of the 256 channels per wave
     constexpr int NT = 16, NC = NT, NH = NT + 2, NG = NT;
     __shared__ __attribute__((aligned(16))) float lds[RB_C * (NC + NH + NG)];
     __shared__ unsigned s_slot, s_dead, s_launch;
@@ -131,25 +135,25 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
     const int g = lane >> 4, c16 = lane & 15;
     const int L = a.L;
     const int n_tiles = a.tiles_per_b * a.B;
-    const int n_slots = n_tiles * DT_TEAM;
+    const int n_slots = n_tiles * TEAM;
     if (tid == 0) {
         s_slot = __hip_atomic_fetch_add(a.sync, 1u, DP_RLX_AGENT);   // tickets in START order
         s_launch = __hip_atomic_load(a.sync + 2, DP_RLX_AGENT);
         s_dead = 0u;
     }
     __syncthreads();
-    // ticket -> (tile, member).  Consecutive workgroups go to consecutive XCDs (8 of them): the four members of a tile are
-    // tickets t, t+8, t+16, t+24 of a run of 32, so that a team shares one XCD's L2 when dispatch follows ticket order.
+    // ticket -> (tile, member).  Consecutive workgroups go to consecutive XCDs (8 of them): the members of a tile are
+    // tickets t, t+8, ... of a run of 8 * TEAM, so that a team shares one XCD when dispatch follows ticket order.
     // Speed only: any bijection is correct.
     const int slot = (int)(s_slot % (unsigned)n_slots);
-    const int full = (n_tiles / 8) * 32;
+    const int full = (n_tiles / 8) * (8 * TEAM);
     int tile, member;
     if (slot < full) {
-        tile = (slot / 32) * 8 + (slot & 7);
-        member = (slot >> 3) & 3;
+        tile = (slot / (8 * TEAM)) * 8 + (slot & 7);
+        member = (slot >> 3) % TEAM;
     } else {
-        tile = (n_tiles / 8) * 8 + (slot - full) / DT_TEAM;
-        member = (slot - full) % DT_TEAM;
+        tile = (n_tiles / 8) * 8 + (slot - full) / TEAM;
+        member = (slot - full) % TEAM;
     }
     const unsigned launch_no = s_launch;
     const int b = tile / a.tiles_per_b, jt = tile - b * a.tiles_per_b;
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
     const bool has_left = jt > 0, has_right = jt + 1 < a.tiles_per_b;
     const int f = l0 + c16;
     const bool fvalid = f < L;
-    const int cb = 4 * member + w;     // this wave's 16-row block of the 256 channels
+    const int cb = NWV * member + w;   // this wave's 16-row block of the 256 channels
     const int ch0 = 16 * cb;
     auto row_of = [&](int r) { return ch0 + 4 * g + r; };
 
@@ -166,8 +170,8 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
         const float *cbp = a.cond + (size_t)b * RB_C * L;
         if (VEC4) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {   // 256 rows x 4 float4
-                const int idx = tid + k * 256;
+            for (int k = 0; k < 1024 / NTHR; ++k) {   // 256 rows x 4 float4
+                const int idx = tid + k * NTHR;
                 const int row = idx >> 2, c4 = idx & 3;
                 const int f0 = l0 + 4 * c4;
                 const bool ok = f0 < L;
@@ -177,8 +181,8 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {   // 256 rows x 16 frames
-                const int idx = tid + k * 256;
+            for (int k = 0; k < 4096 / NTHR; ++k) {   // 256 rows x 16 frames
+                const int idx = tid + k * NTHR;
                 const int row = idx >> 4, cc = idx & 15;
                 const float v = cbp[(size_t)row * L + min(l0 + cc, L - 1)];
                 condT[d16_at<NC>(row, cc)] = l0 + cc < L ? v : 0.f;
@@ -186,8 +190,8 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
         }
         const float *xb = a.x_t + (size_t)b * a.M * L;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {   // 96 rows (M = 80 padded) x 16 frames -> hT rows 0..95, col c <-> frame l0+c
-            const int idx = tid + k * 256;
+        for (int k = 0; k < 1536 / NTHR; ++k) {   // 96 rows (M = 80 padded) x 16 frames -> hT rows 0..95, col c <-> frame l0+c
+            const int idx = tid + k * NTHR;
             const int row = idx >> 4, c = idx & 15;
             const float v = xb[(size_t)min(row, a.M - 1) * L + min(l0 + c, L - 1)];
             hT[d16_at<NH>(row, c)] = (row < a.M && l0 + c < L) ? v : 0.f;
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
         }
         // ------------------------------------------------------------ gather all 256 channels of h incl. the halo columns
         if (s_dead == 0u) {
-            if (!dt_gather<NH, NH>(Hbuf + (size_t)par * h_par + (size_t)tile * RB_C * NH, hT, epoch, tid, has_left ? -1 : 0,
+            if (!dt_gather<NH, NH, NTHR>(Hbuf + (size_t)par * h_par + (size_t)tile * RB_C * NH, hT, epoch, tid, has_left ? -1 : 0,
                                    has_right ? -1 : NH - 1, a.spin_limit))
                 failed(1u + (unsigned)l);
         }
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
             d16_preload<1, D16IterK1>(ringA, apn);
         }
         if (s_dead == 0u) {
-            if (!dt_gather<NG, NG>(Gbuf + (size_t)par * g_par + (size_t)tile * RB_C * NG, gT, epoch, tid, -1, -1, a.spin_limit))
+            if (!dt_gather<NG, NG, NTHR>(Gbuf + (size_t)par * g_par + (size_t)tile * RB_C * NG, gT, epoch, tid, -1, -1, a.spin_limit))
                 failed(1u + (unsigned)l);
         }
         __syncthreads();   // gT complete (and every wave is done with hT: the next layer's gather may overwrite it)
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
     }
     __syncthreads();   // last GEMM 3 done reading gT
     if (s_dead == 0u) {
-        if (!dt_gather<NG, NG>(Gbuf + (size_t)parT * g_par + (size_t)tile * RB_C * NG, gT, epochT, tid, -1, -1, a.spin_limit))
+        if (!dt_gather<NG, NG, NTHR>(Gbuf + (size_t)parT * g_par + (size_t)tile * RB_C * NG, gT, epochT, tid, -1, -1, a.spin_limit))
             failed(1u + (unsigned)a.NL);
     }
     __syncthreads();
@@ -352,13 +356,13 @@ __global__ __launch_bounds__(256, 2) void denoiser_team16_kernel(PersistArgs a)
             __hip_atomic_store(mine + (size_t)row_of(r) * NH + 1 + c16, tagged(epochT, fmaxf(acc[0][r], 0.f)), DP_RLX_AGENT);
     }
     if (s_dead == 0u) {   // (hT was last read in GEMM 2 of the last layer: free)
-        if (!dt_gather<NH, NH>(Hbuf + (size_t)parT * h_par + (size_t)tile * RB_C * NH, hT, epochT, tid, 0, NH - 1, a.spin_limit))
+        if (!dt_gather<NH, NH, NTHR>(Hbuf + (size_t)parT * h_par + (size_t)tile * RB_C * NH, hT, epochT, tid, 0, NH - 1, a.spin_limit))
             failed(1u + (unsigned)a.NL);
     }
     __syncthreads();
-    // output projection: M rows in 16-row blocks dealt over the team's 16 waves (block rb -> member rb % 4, wave rb / 4)
+    // output projection: M rows in 16-row blocks dealt over the team's 16 waves (block rb -> member rb % TEAM, wave rb / TEAM)
     const int nrb = (a.M + 15) / 16;
-    const int rb = member + DT_TEAM * w;
+    const int rb = member + TEAM * w;
     if (rb < nrb) {
         f32x4 o[1];
 #pragma unroll

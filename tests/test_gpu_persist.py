@@ -31,16 +31,19 @@ def _den(mg, manifest, tmp_path, ms=False):
 
 
 def _pin_width(monkeypatch, nt):
-    """MG_PERSIST_NT pins a tile width; 16: the four-workgroup teams where they fit (denoiser_team16.h), 116: 16-frame
-    tiles with one workgroup per tile (denoiser_persist16.h) everywhere; 328: 32-frame tiles, 8 waves."""
-    monkeypatch.setenv("MG_PERSIST_NT", str(16 if nt == 116 else nt))
+    """MG_PERSIST_NT pins a tile width; 16: teams of workgroups per tile where they fit (denoiser_team16.h: 4 members,
+    else 2), 216: teams of 2 only, 116: 16-frame tiles with one workgroup per tile (denoiser_persist16.h) everywhere;
+    328: 32-frame tiles, 8 waves."""
+    monkeypatch.setenv("MG_PERSIST_NT", str(16 if nt in (116, 216) else nt))
     if nt == 116:
         monkeypatch.setenv("MG_PERSIST_TEAM", "0")
+    elif nt == 216:
+        monkeypatch.setenv("MG_PERSIST_TEAM", "2")
     else:
         monkeypatch.delenv("MG_PERSIST_TEAM", raising=False)
 
 
-@pytest.mark.parametrize("nt", [16, 116, 32, 64, 328])
+@pytest.mark.parametrize("nt", [16, 216, 116, 32, 64, 328])
 @pytest.mark.parametrize("ms", [False, True])
 def test_single_launch_forward_vs_oracle_and_per_layer_path(mg, manifest, tmp_path, monkeypatch, ms, nt):
     _pin_width(monkeypatch, nt)     # every tile width, whatever the heuristic would pick
@@ -185,7 +188,7 @@ def test_in_kernel_noise_streams_never_repeat(mg, manifest, tmp_path):
     den.check()
 
 
-@pytest.mark.parametrize("nt", [16, 116, 32, 64])
+@pytest.mark.parametrize("nt", [16, 216, 116, 32, 64])
 def test_handoff_timeout_poisons_the_output_and_raises(mg, manifest, tmp_path, monkeypatch, nt):
     """A neighbour that never sends its edge column (test hook MG_PERSIST_FLAGS bit 1) with the wait bounded to a few
     polls: the kernel must drain (not hang), its output must be NaN (not a plausible mel), the failure must reach the
@@ -207,7 +210,7 @@ def test_handoff_timeout_poisons_the_output_and_raises(mg, manifest, tmp_path, m
         monkeypatch.delenv("MG_PERSIST_SPIN_LIMIT")
         monkeypatch.delenv("MG_PERSIST_FLAGS")
         torch.cuda.synchronize()                  # returns: every workgroup exited
-        assert torch.isnan(bad[:, 0, :, :nt % 100]).all(), "the tile that timed out wrote a result"
+        assert torch.isnan(bad[:, 0, :, :16 if nt in (116, 216) else nt]).all(), "the tile that timed out wrote a result"
         assert not torch.isfinite(bad).all()
         st = den.persist_status(B, L, ws=ws)
         assert st["error"] != 0 and st["ticket"] == 0 and st["done"] == 0 and st["launches"] >= 2, st
@@ -343,14 +346,15 @@ def test_paired_forwards_match_separate_launches(mg, manifest, tmp_path, ms, Bh,
     assert torch.equal(again[0], out_a) and torch.equal(again[1], out_b)
 
 
+@pytest.mark.parametrize("team", ["4", "2"])
 @pytest.mark.parametrize("ms", [False, True])
-def test_team_kernel_one_utterance(mg, manifest, tmp_path, monkeypatch, ms):
+def test_team_kernel_one_utterance(mg, manifest, tmp_path, monkeypatch, ms, team):
     """denoiser_team16.h: four workgroups per 16-frame tile, each owning 64 channels, h and g all-gathered through tagged
     granules every layer.  One 1000-frame utterance = 252 workgroups that wait for each other: the result must match the
     launch-per-layer kernels and the one-workgroup-per-tile kernel, be bit-identical launch after launch (also with a
     second stream saturating HBM next to it), and an utterance inside a small batch must equal the utterance alone."""
     monkeypatch.delenv("MG_PERSIST_NT", raising=False)
-    monkeypatch.delenv("MG_PERSIST_TEAM", raising=False)
+    monkeypatch.setenv("MG_PERSIST_TEAM", team)        # 4 members of 64 channels, or 2 of 128 (what 65-128 tiles use)
     den, W = _den(mg, manifest, tmp_path, ms)
     gen = torch.Generator(device="cuda").manual_seed(61)
     B, L = 1, 1000
@@ -367,7 +371,7 @@ def test_team_kernel_one_utterance(mg, manifest, tmp_path, monkeypatch, ms):
         monkeypatch.setenv("MG_DENOISER_PERSIST", "0")
         per_layer = den(x, t, cond, spk)
         monkeypatch.delenv("MG_DENOISER_PERSIST")
-        monkeypatch.delenv("MG_PERSIST_TEAM")
+        monkeypatch.setenv("MG_PERSIST_TEAM", team)
         assert_close(out.cpu(), per_layer.cpu(), TOL, "team kernel vs per-layer kernels")
         assert_close(out.cpu(), whole_tiles.cpu(), TOL, "team kernel vs one workgroup per tile")
         ref = R.denoiser_forward(W, "", x.cpu(), t.cpu(), cond.cpu(), None if spk is None else spk.cpu())
@@ -399,4 +403,9 @@ def test_team_kernel_one_utterance(mg, manifest, tmp_path, monkeypatch, ms):
         tb = torch.cat([t, torch.randint(0, 1000, (15,), device="cuda", generator=gen)])
         big = den(xb, tb, cb, sb)
         assert torch.equal(big[0], out[0]), "team kernel vs the same utterance in a B=16 batch (64-frame tiles)"
+        # two utterances of 1000 frames (126 tiles): teams of 2 by the launcher's own choice; each equals the utterance alone
+        monkeypatch.delenv("MG_PERSIST_TEAM")
+        two = den(xb[:2].contiguous(), tb[:2].contiguous(), cb[:2].contiguous(), None if sb is None else sb[:2].contiguous())
+        assert torch.equal(two[0], out[0]) and torch.equal(two[1], big[1])
+        monkeypatch.setenv("MG_PERSIST_TEAM", team)
     den.check()
