@@ -93,10 +93,13 @@ class FlatAdam(torch.optim.Adam):
     def __init__(self, bucket, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, param_order=None):
         """param_order: the parameter list a stock optimizer would have been built over (e.g. `model.parameters()`,
         utils/model.py:33) -- it fixes the index order of `state_dict()`, which is how checkpoints address the state;
-        the flat layout follows the bucket either way.  Must name exactly the bucket's parameters."""
+        the flat layout follows the bucket either way.  Must contain every parameter of the bucket (extras, e.g. frozen
+        parameters, keep their index but are never stepped)."""
         order = list(param_order) if param_order is not None else list(bucket.params)
-        if {id(p) for p in order} != {id(p) for p in bucket.params} or len(order) != len(bucket.params):
-            raise ValueError("param_order must list exactly the parameters of the bucket")
+        # a superset is fine: parameters outside the bucket (requires_grad=False -- the decoder's position table --
+        # sit in the reference's Adam too, without ever getting state) only hold their index in state_dict()
+        if not {id(p) for p in bucket.params} <= {id(p) for p in order} or len({id(p) for p in order}) != len(order):
+            raise ValueError("param_order must list every parameter of the bucket, each once")
         super().__init__(order, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.bucket = bucket
         flat = bucket.flat

@@ -48,12 +48,12 @@ class HotPathTrainer:
         # utils/model.py:32-40: Adam(lr, betas) per network.  On the GPU: FlatAdam (optimizer.py) -- parameters and
         # moments flat like the gradients, clip + step in two launches; on CPU (tests) torch's own.  Either way
         # state_dict() indexes the parameters in g_param_order / g_params order, NOT in the bucket's layout order.
-        order_g = list(g_param_order) if g_param_order is not None else [p for p in g_params if p.requires_grad]
+        order_g = list(g_param_order) if g_param_order is not None else g_params
         if self.bucketG.flat.is_cuda:
             diffusion.denoise_fn.bind_grad_buffer(self.bucketG.flat, self.bucketG.offsets)
             self.optG = FlatAdam(self.bucketG, lr=oc["init_lr_G"], betas=oc["betas"], param_order=order_g)
             self.optD = FlatAdam(self.bucketD, lr=oc["init_lr_D"], betas=oc["betas"],
-                                 param_order=[p for p in discriminator.parameters() if p.requires_grad])
+                                 param_order=list(discriminator.parameters()))
         else:
             self.optG = torch.optim.Adam(order_g, lr=oc["init_lr_G"], betas=oc["betas"])
             self.optD = torch.optim.Adam(discriminator.parameters(), lr=oc["init_lr_D"], betas=oc["betas"])
