@@ -318,23 +318,27 @@ def test_default_trainer_state_dict_is_in_parameters_order(mg, manifest, tmp_pat
     assert not torch.equal(stock.state[a]["exp_avg"], stock.state[b]["exp_avg"])
 
 
-def test_step_from_model_shallow_paired_equals_unpaired(mg, manifest, tmp_path):
-    """`--model shallow` through step_from_model: the decoder / PostNet run in train mode inside both model calls (their
-    dropout masks differ between the calls, so the D phase and the G phase see different coarse mels), slot 15 keeps the
-    decoder's graph (postnet_loss trains decoder / PostNet / encoder, model/loss.py:165-167), the mel loss targets the
-    detached coarse mel (model/loss.py:168-170), lambda_fm_shallow weighs the FM term.  With every random source pinned in
-    call order, one launch for both generator forwards (pair=True) must give the step of two launches."""
+@pytest.mark.parametrize("kind,ms", [("shallow", False), ("naive", True)])
+def test_step_from_model_paired_equals_unpaired(mg, manifest, tmp_path, kind, ms):
+    """step_from_model through the model variants the first test does not reach.
+    shallow: the decoder / PostNet run in train mode inside both model calls (their dropout masks differ between the calls,
+    so the D phase and the G phase see different coarse mels), slot 15 keeps the decoder's graph (postnet_loss trains
+    decoder / PostNet / encoder, model/loss.py:165-167), the mel loss targets the detached coarse mel (:168-170),
+    lambda_fm_shallow weighs the FM term.  multi-speaker naive: the speaker embedding is a trained table whose rows reach the
+    denoiser and the discriminator of both phases.  With every random source pinned in call order, one launch for both
+    generator forwards (pair=True) must give the step of two launches; `upstream_loss` reaches the encoder;
+    evaluate_from_model returns the same loss names without touching a weight."""
     from oracle import weights as WR
     seen = {}
     for pair in (False, True):
         e = golden("elementwise")
-        stats = write_stats(tmp_path, e["spec_min"], e["spec_max"])
-        args, pre, mc, tr = hot_path_configs("shallow", 4, stats_dir=stats)
+        stats = write_stats(tmp_path, e["spec_min"], e["spec_max"], n_speakers=5 if ms else 0)
+        args, pre, mc, tr = hot_path_configs(kind, 4, multi_speaker=ms, stats_dir=stats)
         B, L = 2, 48
         enc = DropoutEncoder(L)
         enc.drop.p = 0.0
         model = mg.MixGANTTS(args, pre, mc, tr, linguistic_encoder=enc)
-        w = WR.draw(manifest["mixgantts_shallow_ms0"]["seeded"], 61)
+        w = WR.draw(manifest["mixgantts_%s_ms%d" % (kind, ms)]["seeded"], 61)
         sd = model.state_dict()
         for k, a in w.items():
             if k in sd and tuple(sd[k].shape) == a.shape:
@@ -343,35 +347,43 @@ def test_step_from_model_shallow_paired_equals_unpaired(mg, manifest, tmp_path):
         with torch.no_grad():
             model.diffusion.denoise_fn.output_projection.conv.weight.normal_(0, 0.05, generator=torch.Generator().manual_seed(3))
         D = mg.JCUDiscriminator(pre, mc, tr)
-        load_seeded(D, manifest, "jcu_ms0", 62)
+        load_seeded(D, manifest, "jcu_ms%d" % ms, 62)
         model, D = model.cuda().train(), D.cuda()
         gen = torch.Generator().manual_seed(12)
         mel_lens = torch.tensor([L, L - 8])
         mels = (torch.rand(B, L, 80, generator=gen) * 13.5 - 11.5) * (torch.arange(L)[None, :] < mel_lens[:, None]).unsqueeze(-1)
         cu = lambda a: a.cuda()  # noqa: E731
-        batch = [["a", "b"], ["t"] * B, cu(torch.zeros(B, dtype=torch.long)), cu(torch.ones(B, 5, dtype=torch.long)),
+        batch = [["a", "b"], ["t"] * B, cu(torch.tensor([1, 3])), cu(torch.ones(B, 5, dtype=torch.long)),
                  cu(torch.full((B,), 5)), 5, cu(torch.ones(B, 3, dtype=torch.long)), cu(torch.full((B,), 3)), 3, None, None,
                  cu(mels), cu(mel_lens), L, cu(torch.zeros(B, 5)), cu(torch.zeros(B, 5)), cu(torch.ones(B, 3, dtype=torch.long))]
-        tapes = [[torch.tensor([3, 1])] + [torch.randn(B, 1, 80, L, generator=gen) for _ in range(3)] for _ in range(2)]
+        tapes = [[torch.tensor([3, 1])] + [torch.randn(B, 1, 80, L, generator=gen) for _ in range(3)] for _ in range(4)]
         _tape_trainer(model.diffusion, tapes)
         mgen = torch.Generator().manual_seed(99)      # the transformer's dropout keep-masks, in call order
         mg.transformer.DROPOUT_FN = lambda shape, p, device: (torch.rand(shape, generator=mgen) >= p).to(device)
         try:
             others = [p for n, p in model.named_parameters() if not n.startswith("diffusion.")]
             trainer = mg.HotPathTrainer(model.diffusion, D, tr, mc, extra_g_params=others, g_param_order=list(model.parameters()))
+            weights0 = [p.detach().clone() for p in list(model.parameters()) + list(D.parameters())]
+            ev = trainer.log_scalars(trainer.evaluate_from_model(model, list(batch)))
+            assert all(torch.equal(a, b) for a, b in zip(weights0, list(model.parameters()) + list(D.parameters())))
+            assert all(p.grad is None for p in model.parameters())
             got = {}
             trainer.grad_hook = _recording_hook(got, model, D)
-            dec0 = model.decoder.layer_stack[0].slf_attn.w_qs.weight.detach().clone()
-            out = trainer.step_from_model(model, batch, pair=pair)
+            upstream = lambda batch_, output, step: 0.25 * (enc.table ** 2).mean()  # noqa: E731
+            out = trainer.step_from_model(model, batch, upstream_loss=upstream, pair=pair)
         finally:
             mg.transformer.DROPOUT_FN = None
-        assert model.diffusion.noise_fn.i == 6 and model.diffusion.t_fn.i == 2
+        assert model.diffusion.noise_fn.i == 12 and model.diffusion.t_fn.i == 4
         vals = trainer.log_scalars(out)
-        assert set(vals) >= {"d_loss", "adv_loss", "mel_loss", "fm_loss", "postnet_loss"}
-        assert all(np.isfinite(v) for v in vals.values()) and vals["postnet_loss"] > 0
-        assert not torch.equal(model.decoder.layer_stack[0].slf_attn.w_qs.weight.detach(), dec0), "postnet_loss trains the decoder"
-        assert got["G"]["decoder.layer_stack.0.slf_attn.w_qs.weight"].abs().sum() > 0
+        want = {"d_loss", "adv_loss", "mel_loss", "fm_loss"} | ({"postnet_loss"} if kind == "shallow" else set())
+        assert set(vals) >= want and set(ev) >= want
+        assert all(np.isfinite(v) for v in list(vals.values()) + list(ev.values()))
         assert got["G"]["linguistic_encoder.table"].abs().sum() > 0
+        if kind == "shallow":
+            assert vals["postnet_loss"] > 0 and got["G"]["decoder.layer_stack.0.slf_attn.w_qs.weight"].abs().sum() > 0
+        if ms:
+            assert got["G"]["speaker_emb.weight"][[1, 3]].abs().sum() > 0          # the two speakers of the batch ...
+            assert float(got["G"]["speaker_emb.weight"][[0, 2, 4]].abs().sum()) == 0.0   # ... and nobody else
         seen[pair] = (vals, got)
     for k, v in seen[False][0].items():
         assert abs(seen[True][0][k] - v) <= 5e-5 * max(1.0, abs(v)), k
