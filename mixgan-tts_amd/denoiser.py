@@ -168,7 +168,9 @@ class Denoiser(nn.Module):
         pending backward: autograd.DenoiserFn keeps it in ctx; a captured graph: new_workspace) holds the tensor
         itself, so evicting an entry never frees memory that is still referenced.  A save=True workspace whose
         backward has not run yet (`_mg_busy`) is not handed out again: the next grad-enabled forward gets a fresh one."""
-        k = (B, L, bool(save), dev)
+        # keyed by stream too: the single-launch kernels keep their tickets and hand-off buffers in the workspace, so two
+        # launches in flight on different streams must not share one
+        k = (B, L, bool(save), dev, torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0)
         ws = self._ws.get(k)
         if ws is not None and not (save and getattr(ws, "_mg_busy", False)):
             self._ws.move_to_end(k)
@@ -353,7 +355,7 @@ class Denoiser(nn.Module):
         NL = d.n_layers
         raise_if_failed((self,))
         packed = self.packed_weights(with_backward=True)
-        k = (B, L, dev)
+        k = (B, L, dev, torch.cuda.current_stream(dev).cuda_stream)
         bws = self._bws.get(k)
         if bws is None:
             # transient scratch of this call only (stream-ordered), so eviction is always safe
