@@ -149,7 +149,7 @@ struct DenWs {
     // single-launch forward (denoiser_persist.h): 64 floats of counters (must be ZERO when the workspace is first used;
     // the kernel re-arms them itself) and the halo hand-off granules [2][tiles][2][C] x 8 bytes
     size_t sync, gran;
-    size_t team;   // denoiser_team16.h: gather buffers of the four-workgroup teams (small launches only; zero at first use)
+    size_t team;   // denoiser_team16.h: gather buffers of the workgroup teams (small launches only; zero at first use)
 };
 
 // 32-frame tiles of the single-launch forward

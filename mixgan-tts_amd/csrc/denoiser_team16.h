@@ -1,23 +1,24 @@
 // The single-launch Denoiser.forward / p_sample for ONE utterance (or a handful of short ones): a 16-frame tile is
-// computed by a TEAM of four workgroups, each owning 64 of the 256 residual channels.
+// computed by a TEAM of four (or two) workgroups, each owning 64 (128) of the 256 residual channels.
 //
 // Why: with a whole 256-channel tile per workgroup (denoiser_persist16.h) one 1000-frame utterance is 63 workgroups on 256
 // CUs, and every one of them streams all 55 MB of weights through its own L1 and runs all 23.8 MFLOP per frame on one CU:
 // 0.87 ms per reverse step, 27 TFLOP/s.  synthesize.py-style serving is exactly this shape (batch 1).  Here workgroup
-// (tile, m) computes the output rows of its channels 64m .. 64m+63 in all three GEMMs of a layer -- a quarter of the
-// weight stream and of the MFMAs per CU, 252 workgroups -- and the team all-gathers what a layer's next GEMM reduces
-// over (all 256 channels of h, then of the gate product g) through tagged 8-byte granules in global memory, the same
-// "the data is the flag" hand-off the wider kernels use for their halo columns (cdna_hip_programming.md section 6,
-// Guideline 16, form R2).  The k=3 halo rides on the same exchange: a workgroup writes the edge columns of its h rows
-// straight into the neighbouring tiles' gather buffers.
+// (tile, m) computes the output rows of its channels in all three GEMMs of a layer -- a quarter of the weight stream and of
+// the MFMAs per CU, 252 workgroups -- and the team all-gathers what a layer's next GEMM reduces over (all 256 channels of
+// h, then of the gate product g) through tagged 8-byte granules in global memory, the same "the data is the flag" hand-off
+// the wider kernels use for their halo columns (cdna_hip_programming.md section 6, Guideline 16, form R2).  The k=3 halo
+// rides on the same exchange: a workgroup writes the edge columns of its h rows straight into the neighbouring tiles'
+// gather buffers.
 //
-// Per layer and workgroup: 2 publishes (64 channels x 16 columns) and 2 gathers (256 x 18, 256 x 16 granules) against
-// a quarter of a tile's MFMAs.  x and the skip sum of the workgroup's channels stay in registers for all layers (one
+// Per layer and workgroup: 2 publishes (its channels x 16 columns) and 2 gathers (256 x 18, 256 x 16 granules) against
+// its share of a tile's MFMAs.  x and the skip sum of the workgroup's channels stay in registers for all layers (one
 // 16-row block per wave); cond, h and g tiles in LDS (50 KB).  Fragments, packs and LDS layout as in
-// denoiser_persist16.h (v_mfma_f32_16x16x4_f32).
+// denoiser_persist16.h (v_mfma_f32_16x16x4_f32); every GEMM reduces in the order of the wider kernels, so an utterance
+// computed by teams is bit-identical to the same utterance inside a large batch.
 //
-// Forward progress: the four workgroups of a team and the teams of neighbouring tiles wait for each other inside the
-// launch, so the whole grid must be co-resident: the launcher uses this kernel only when tiles x 4 <= the CU count.
+// Forward progress: the workgroups of a team and the teams of neighbouring tiles wait for each other inside the launch,
+// so the whole grid must be co-resident: the launcher uses this kernel only when tiles x team size <= the CU count.
 // Every wait is bounded (dp_fail: sticky error word, host-visible word, NaN output), as in the wider kernels.
 #pragma once
 #include "denoiser_persist16.h"
