@@ -201,6 +201,9 @@ typedef struct {
 #define MG_DEN_BACKWARD 1 /* also pack the transposed (data-gradient) forms mg_denoiser_bwd consumes */
 #define MG_DEN_SPLIT 2    /* also pack hi/lo bf16 pairs for the split-precision forward */
 #define MG_DEN_P16 4      /* also pack the 16x16x4-MFMA forms: the 16-frame tile width of the single-launch forward */
+#define MG_DEN_JOBS_RESIDENT 8 /* mg_denoiser_pack only: the previous call had the same weight pointers, flags and `packed`
+                                * buffer -- its job table is still in the buffer's tail, skip the host-to-device copy
+                                * (the one host transfer of a training step: without it the step is hipGraph-capturable) */
 /* flags for mg_denoiser_fwd's `mode` */
 #define MG_FWD_SAVE 1     /* keep per-layer activations for mg_denoiser_bwd (fp32 path only) */
 #define MG_FWD_SPLIT 2    /* residual-layer GEMMs as 3-term bf16-split MFMA products (fp32-grade, ~1e-5) */
@@ -402,6 +405,11 @@ size_t mg_grad_norm_scratch_floats(void);
 int mg_grad_norm(const float *g, size_t n, float max_norm, float *scratch, float *out, void *stream);
 int mg_adam_flat(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, long step, const float *grad_scale, void *stream);
+/* Same; hyper (device, 2 floats, or NULL) = {lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step)} is read by the kernel
+ * instead of the values derived from the lr / step arguments -- a captured hipGraph of a training step replays this launch
+ * with the numbers the host wrote there before the replay (HotPathTrainer.capture). */
+int mg_adam_flat_dev(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, long step, const float *grad_scale, const float *hyper, void *stream);
 
 /* ------------------------------------------------------------------ losses on the path (model/loss.py)
  * mg_loss_sum: out[0] = sum (a-c)^2 (mode 0: F.mse_loss against a constant label, loss.py:14-19)

@@ -24,7 +24,7 @@ EXPORTS = (
     "mg_length_regulate_fwd", "mg_length_regulate_bwd", "mg_word_pool_fwd", "mg_word_pool_bwd", "mg_mapping_mask",
     "mg_rel_coef", "mg_resblock_fwd", "mg_gate_bwd", "mg_mish_fwd", "mg_mish_bwd", "mg_step_embed",
     "mg_denoiser_psample", "mg_denoiser_persist_status", "mg_persist_error", "mg_denoiser_fwd_pair",
-    "mg_grad_norm_scratch_floats", "mg_grad_norm", "mg_adam_flat",
+    "mg_grad_norm_scratch_floats", "mg_grad_norm", "mg_adam_flat", "mg_adam_flat_dev",
     "mg_multi_loss_scratch_floats", "mg_multi_loss_fwd", "mg_multi_loss_bwd",
 )
 
@@ -136,6 +136,7 @@ def _declare(L):
         "mg_grad_norm_scratch_floats": (sz, []),
         "mg_grad_norm": (i, [vp, sz, f, vp, vp, vp]),
         "mg_adam_flat": (i, [vp, vp, vp, vp, sz, f, f, f, f, f, lg, vp, vp]),
+        "mg_adam_flat_dev": (i, [vp, vp, vp, vp, sz, f, f, f, f, f, lg, vp, vp, vp]),
         "mg_loss_grad": (i, [vp, vp, f, i, vp, f, sz, vp, vp]),
         "mg_mel_l1_fwd": (i, [vp, vp, vp, i, i, vp, vp]),
         "mg_mel_l1_bwd": (i, [vp, vp, vp, i, i, vp, vp, vp, vp]),

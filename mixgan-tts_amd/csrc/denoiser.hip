@@ -296,8 +296,10 @@ extern "C" int mg_denoiser_pack(const mg_denoiser_dims *d, const float *const *w
         // the table travels in the reserved tail of the packed buffer (host memory is pageable: the runtime stages
         // the 30 KB copy, after which `jobs` may be reused)
         PackJob *dev_jobs = reinterpret_cast<PackJob *>(packed + o.jobs);
-        hipError_t e = hipMemcpyAsync(dev_jobs, jobs, (size_t)n * sizeof(PackJob), hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) return (int)e;
+        if (!(flags & MG_DEN_JOBS_RESIDENT)) {   // (a caller repacking the same tensors into the same buffer skips the copy)
+            hipError_t e = hipMemcpyAsync(dev_jobs, jobs, (size_t)n * sizeof(PackJob), hipMemcpyHostToDevice, st);
+            if (e != hipSuccess) return (int)e;
+        }
         hipLaunchKernelGGL(pack_table_kernel, dim3(blocks), dim3(256), 0, st, dev_jobs, n, packed);
         MG_LAUNCH_CHECK();
     }

@@ -414,6 +414,8 @@ struct AdamArgs {
     const float *scale;   // device scalar multiplied into g (the clip factor), or null
     size_t n;
     float lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, weight_decay;
+    const float *hyper;   // optional device pair {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)} read instead of the two above:
+                          // a captured hipGraph replays this launch with the step count and lr of the moment
 };
 
 __device__ __forceinline__ void adam_one(float &p, float &m, float &v, float g, const AdamArgs &a)
@@ -427,6 +429,10 @@ __device__ __forceinline__ void adam_one(float &p, float &m, float &v, float g, 
 
 __global__ __launch_bounds__(256) void adam_flat_kernel(AdamArgs a)
 {
+    if (a.hyper) {
+        a.lr_over_bc1 = a.hyper[0];
+        a.inv_sqrt_bc2 = a.hyper[1];
+    }
     const float sc = a.scale ? a.scale[0] : 1.f;
     const size_t n4 = a.n >> 2, stride = (size_t)gridDim.x * 256;
     f32x4 *p4 = reinterpret_cast<f32x4 *>(a.p), *m4 = reinterpret_cast<f32x4 *>(a.m), *v4 = reinterpret_cast<f32x4 *>(a.v);
@@ -471,6 +477,13 @@ extern "C" int mg_grad_norm(const float *g, size_t n, float max_norm, float *scr
 extern "C" int mg_adam_flat(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1, float beta2,
                             float eps, float weight_decay, long step, const float *grad_scale, void *stream)
 {
+    return mg_adam_flat_dev(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, nullptr, stream);
+}
+
+extern "C" int mg_adam_flat_dev(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1, float beta2,
+                                float eps, float weight_decay, long step, const float *grad_scale, const float *hyper,
+                                void *stream)
+{
     if (!p || !g || !m || !v) return MG_ERR_ARG;
     if (n == 0 || step < 1) return MG_ERR_SHAPE;
     if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return MG_ERR_ARG;
@@ -480,6 +493,7 @@ extern "C" int mg_adam_flat(float *p, const float *g, float *m, float *v, size_t
     a.v = v;
     a.g = g;
     a.scale = grad_scale;
+    a.hyper = hyper;
     a.n = n;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     a.lr_over_bc1 = (float)((double)lr / bc1);

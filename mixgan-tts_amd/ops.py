@@ -12,8 +12,8 @@ ACT = {None: 0, "none": 0, "relu": 1, "lrelu": 2, "tanh": 3, "lrelu_s": 4}
 PACK_PLAIN, PACK_GATE, PACK_DGRAD = 0, 1, 2
 
 
-def pack_conv_weight(w, mode=PACK_PLAIN):
-    """[Co, Ci, K] (or [Co, Ci]) fp32 -> MFMA-fragment-ordered cache tensor."""
+def pack_conv_weight(w, mode=PACK_PLAIN, out=None):
+    """[Co, Ci, K] (or [Co, Ci]) fp32 -> MFMA-fragment-ordered cache tensor (into `out` when it fits)."""
     L = _lib.lib()
     if w.dim() == 2:
         w = w[:, :, None]
@@ -22,7 +22,8 @@ def pack_conv_weight(w, mode=PACK_PLAIN):
     n = L.mg_conv_packed_floats(Co, Ci, K, mode)
     if n == 0:
         raise _lib.MixganHipError("unsupported conv weight shape %s" % (tuple(w.shape),))
-    out = torch.empty(n, device=w.device, dtype=torch.float32)
+    if out is None or out.numel() != n or out.device != w.device:
+        out = torch.empty(n, device=w.device, dtype=torch.float32)
     check(L.mg_conv_pack(fptr(w), fptr(out), Co, Ci, K, mode, stream_ptr()))
     return out
 
@@ -38,7 +39,8 @@ def pack_cached(w, mode=PACK_PLAIN):
     hit = cache.get(key)
     if hit is not None and hit[0] == owner._version:
         return hit[1]
-    p = pack_conv_weight(w, mode)
+    # refreshed IN PLACE when the buffer exists: launches captured in a hipGraph keep reading the same address
+    p = pack_conv_weight(w, mode, out=None if hit is None else hit[1])
     cache[key] = (owner._version, p)
     return p
 
@@ -467,8 +469,10 @@ def grad_norm(flat, max_norm, out=None, scratch=None):
     return out
 
 
-def adam_flat(p, g, m, v, lr, betas, eps, weight_decay, step, grad_scale=None):
-    """One torch.optim.Adam step on flat buffers, in place on p, m, v; g * grad_scale[0] is the gradient used."""
+def adam_flat(p, g, m, v, lr, betas, eps, weight_decay, step, grad_scale=None, hyper=None):
+    """One torch.optim.Adam step on flat buffers, in place on p, m, v; g * grad_scale[0] is the gradient used.
+    hyper: device pair {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)} read by the kernel instead of lr / step (graphs)."""
     L = _lib.lib()
-    check(L.mg_adam_flat(fptr(p), fptr(g), fptr(m), fptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]),
-                         float(eps), float(weight_decay), int(step), fptr(grad_scale, True), stream_ptr()))
+    check(L.mg_adam_flat_dev(fptr(p), fptr(g), fptr(m), fptr(v), p.numel(), float(lr), float(betas[0]), float(betas[1]),
+                             float(eps), float(weight_decay), int(step), fptr(grad_scale, True), fptr(hyper, True),
+                             stream_ptr()))

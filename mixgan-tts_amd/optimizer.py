@@ -111,6 +111,7 @@ class FlatAdam(torch.optim.Adam):
         self._norm = torch.zeros(2, device=flat.device, dtype=torch.float32)
         self._scratch = None
         self._steps = torch.tensor(0.0)                   # shared by every parameter's state (they step together)
+        self._hyper = None                                # device pair read by the kernel (enable_device_hyper)
         for p in bucket.params:
             off, n = bucket.offsets[id(p)], p.numel()
             home = self.flat_p[off:off + n].view_as(p)
@@ -137,10 +138,30 @@ class FlatAdam(torch.optim.Adam):
             ops.grad_norm(self.bucket.flat, max_grad_norm, out=self._norm, scratch=self._scratch)
             scale = self._norm[1:]
         self._steps += 1
+        if self._hyper is not None and not torch.cuda.is_current_stream_capturing():
+            self.write_hyper()                        # (under capture the replaying side writes it before every replay)
         ops.adam_flat(self.flat_p, self.bucket.flat, self.flat_m, self.flat_v, g["lr"], g["betas"], g["eps"],
-                      g["weight_decay"], int(self._steps.item()), scale)
+                      g["weight_decay"], int(self._steps.item()), scale, hyper=self._hyper)
         torch.autograd.graph.increment_version(self.bucket.params)    # derived caches (packed weights) key on it
         return self._norm if max_grad_norm is not None else None
+
+    def enable_device_hyper(self):
+        """From now on the update kernel reads lr / (1 - beta1^t) and 1 / sqrt(1 - beta2^t) from device memory (written
+        by write_hyper) instead of taking them as launch arguments: a hipGraph that contains step() then replays with the
+        step count and learning rate of the moment (HotPathTrainer.capture)."""
+        if self._hyper is None:
+            self._hyper = torch.zeros(2, device=self.flat_p.device, dtype=torch.float32)
+            self._hyper_host = torch.zeros(2, dtype=torch.float32).pin_memory()
+        return self
+
+    def write_hyper(self, step=None):
+        """Host -> device: the two scalars of the step about to run (step: 1-based count; default: the current one)."""
+        g = self.param_groups[0]
+        t = float(self._steps) if step is None else float(step)
+        b1, b2 = g["betas"]
+        self._hyper_host[0] = g["lr"] / (1.0 - b1 ** t)
+        self._hyper_host[1] = 1.0 / (1.0 - b2 ** t) ** 0.5
+        self._hyper.copy_(self._hyper_host, non_blocking=True)
 
     def adopt(self, adam):
         """Continue from a stock torch.optim.Adam over (a superset of) the same parameter objects -- e.g. the optG /

@@ -99,7 +99,51 @@ class HotPathTrainer:
             total = torch.linalg.vector_norm(bucket.flat)
             bucket.flat.mul_(torch.clamp(self.grad_clip / (total + 1e-6), max=1.0))
             opt.step()
-        opt.zero_grad()                               # after step, as train.py:84-85
+        if self._static_grads and bucket is self.bucketD:
+            # captured step: the discriminator's .grad tensors stay the bucket's views (static addresses) and are zeroed in
+            # place -- the G phase's deposit then ADDS to zeros where train.py:84-85's zero_grad(set_to_none) makes it assign
+            bucket.flat.zero_()
+        else:
+            opt.zero_grad()                           # after step, as train.py:84-85
+
+    _static_grads = False
+
+    def capture(self, mel, cond, spk, mel_pad_mask, coarse_mel=None, warmup=3):
+        """The whole step() -- both generator forwards, four discriminator passes, both backwards, both clip + Adam updates,
+        ~270 launches -- as ONE captured hipGraph, replayed per batch.  The discriminator's half of a step is ~100 small
+        launches per phase that the host issues more slowly than the GPU runs them (section 4.2 of DESIGN.md); a replay
+        has no host in the loop.  Returns a callable with step()'s signature (same shapes as the example batch, tensors
+        copied into static buffers) and return value (the loss tensors are static too: read them before the next call).
+
+        What differs from step(): t / noise come from torch's graph-safe generator state; the optimizers' step counts and
+        learning rates travel through device memory (FlatAdam.enable_device_hyper), so lr schedulers keep working; the
+        discriminator's gradients are zeroed in place instead of set to None (same numbers).  Single process only (the
+        gradient exchange is not captured), grad_acc_step = 1, no grad_hook / t_fn / noise_fn."""
+        if not (isinstance(self.optG, FlatAdam) and isinstance(self.optD, FlatAdam)):
+            raise RuntimeError("capture() needs the GPU trainer (FlatAdam optimizers)")
+        if self.bucketG.exchanging() or self.grad_acc != 1 or self.grad_hook is not None or self.G.t_fn or self.G.noise_fn:
+            raise RuntimeError("capture(): single process, grad_acc_step = 1, no hooks")
+        dev = mel.device
+        static = [None if a is None else a.detach().clone() for a in (mel, cond, spk, mel_pad_mask, coarse_mel)]
+        self.optG.enable_device_hyper()
+        self.optD.enable_device_hyper()
+        self._static_grads = True
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):          # warm-up on the capture stream: workspaces and scratch are keyed by stream
+            for _ in range(max(2, warmup)):
+                self.step(*static)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.check(sync=False)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            out = self.step(*static)
+        # the capture itself ran nothing: undo its host-side bookkeeping (it will be redone per replay)
+        self.optG._steps -= 1
+        self.optD._steps -= 1
+        self.step_no -= 1
+        return _GraphedStep(self, graph, static, out)
 
     def _model_update(self, loss, bucket, opt):
         """train.py:75-85."""
@@ -323,6 +367,30 @@ class HotPathTrainer:
     def end_epoch(self):
         self.sdlG.step()
         self.sdlD.step()
+
+
+class _GraphedStep:
+    """A captured HotPathTrainer.step (HotPathTrainer.capture)."""
+
+    def __init__(self, trainer, graph, static, out):
+        self.trainer, self.graph, self.static, self.out = trainer, graph, static, out
+        self._params = list(trainer.bucketG.params) + list(trainer.bucketD.params)
+
+    def __call__(self, mel, cond, spk, mel_pad_mask, coarse_mel=None):
+        tr = self.trainer
+        for dst, src in zip(self.static, (mel, cond, spk, mel_pad_mask, coarse_mel)):
+            if (dst is None) != (src is None) or (dst is not None and dst.shape != src.shape):
+                raise ValueError("captured step: batch shapes differ from the captured example")
+            if dst is not None and dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        for opt in (tr.optD, tr.optG):         # the step counts / learning rates this replay's updates use
+            opt.write_hyper(float(opt._steps) + 1.0)
+        self.graph.replay()
+        tr.optD._steps += 1
+        tr.optG._steps += 1
+        tr.step_no += 1
+        torch.autograd.graph.increment_version(self._params)     # derived caches (packed weights) of eager users
+        return self.out
 
 
 class _DiffusionInputs(torch.nn.Module):

@@ -390,3 +390,58 @@ def test_step_from_model_paired_equals_unpaired(mg, manifest, tmp_path, kind, ms
     for name in ("D", "G"):
         for k, g in seen[False][1][name].items():
             assert_close(seen[True][1][name][k], g, 2e-4, "%s bucket %s, paired vs unpaired" % (name, k))
+
+
+def test_captured_step_replays_with_live_hyperparameters(mg, manifest, tmp_path):
+    """HotPathTrainer.capture: the whole GAN step as one hipGraph.  Replays must train (weights move, losses finite), count
+    optimizer steps like eager steps do, take the learning rate of the moment from device memory (lr = 0: a replay leaves
+    every weight where it was; an lr-scheduler epoch step shows in the next update), draw fresh t / noise per replay, leave
+    eager users of the modules with current weights (version bump -> repack), and -- with identical weights, data and lr = 0
+    on both sides -- compute the losses an eager step computes in distribution (same data, other random draws: compared
+    through the deterministic part, the discriminator loss at fixed inputs)."""
+    G, D, WG, WD, buf, mel, conds, pad, tapes, tr, mc = _setup(mg, manifest, tmp_path, B=3, L=64)
+    trainer = mg.HotPathTrainer(G, D, tr, mc)
+    melc, condc, padc = mel.cuda(), conds[0].cuda(), pad.cuda()
+    step = trainer.capture(melc, condc, None, padc)
+    n0 = float(trainer.optG._steps)
+    w0 = [p.detach().clone() for p in list(G.parameters()) + list(D.parameters())]
+    outs = []
+    for _ in range(3):
+        out = step(melc, condc, None, padc)
+        outs.append({k: float(v) for k, v in out.items()})
+    assert all(np.isfinite(v) for o in outs for v in o.values())
+    assert outs[0]["mel_loss"] != outs[1]["mel_loss"], "fresh t / noise per replay"
+    assert float(trainer.optG._steps) == n0 + 3 and float(trainer.optD._steps) == n0 + 3 and trainer.step_no == int(n0) + 4
+    w1 = [p.detach().clone() for p in list(G.parameters()) + list(D.parameters())]
+    assert sum(int(not torch.equal(a, b)) for a, b in zip(w0, w1)) > 100
+    # optimizer state reads like a stock Adam's after the same number of steps
+    sd = trainer.optG.state_dict()
+    assert float(sd["state"][0]["step"]) == n0 + 3
+    # eager users see the replayed weights: the module's own forward equals a fresh module loaded with its state_dict
+    x = torch.randn(2, 1, 80, 64, device="cuda")
+    tt = torch.tensor([1, 3], device="cuda")
+    cc = torch.randn(2, 256, 64, device="cuda")
+    with torch.no_grad():
+        y = G.denoise_fn(x, tt, cc, None)
+    args, pre, mc2, tr2 = hot_path_configs("naive", 4, stats_dir=str(tmp_path))
+    fresh = mg.GaussianDiffusion(args, pre, mc2, tr2)
+    fresh.load_state_dict({k: v.detach().cpu() for k, v in G.state_dict().items()})
+    with torch.no_grad():
+        y2 = fresh.cuda().denoise_fn(x, tt, cc, None)
+    assert torch.equal(y, y2), "packed-weight cache of the eager path is stale after replays"
+    # lr = 0 through the ordinary param_groups: a replay must not move a weight
+    for opt in (trainer.optG, trainer.optD):
+        opt.param_groups[0]["lr"] = 0.0
+    step(melc, condc, None, padc)
+    w2 = [p.detach().clone() for p in list(G.parameters()) + list(D.parameters())]
+    assert all(torch.equal(a, b) for a, b in zip(w1, w2)), "the learning rate was baked into the graph"
+    # ... and a nonzero one moves them again, by an update proportional to it
+    for opt, lr in ((trainer.optG, 1e-4), (trainer.optD, 2e-4)):
+        opt.param_groups[0]["lr"] = lr
+    step(melc, condc, None, padc)
+    w3 = [p.detach() for p in list(G.parameters()) + list(D.parameters())]
+    moved = max(float((a - b).abs().max()) for a, b in zip(w2, w3))
+    assert 0 < moved <= 2e-3, moved            # an Adam update is of the order of lr (|m| / sqrt(v) can exceed 1 by a few x)
+    trainer.check()
+    with pytest.raises(ValueError):
+        step(melc[:2], condc[:2], None, padc[:2])
