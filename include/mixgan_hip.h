@@ -235,12 +235,24 @@ int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, const float 
  * draws fresh noise; `noise_stream` (its low 32 bits) must be unique per workspace instance within a process -- the
  * caller numbers its workspaces -- so that two workspaces (another shape, a re-allocated one, another captured graph)
  * never walk the same stream; ranks use different seeds.  x_prev [B, M, L] must not alias x_t; x0_out (optional)
- * receives the pre-clamp x_0.  On the fp32 inference path this is ONE kernel launch. */
+ * receives the pre-clamp x_0.  On the fp32 inference path this is ONE kernel launch.
+ *
+ * cproj (optional, MG_FWD_P16 packs only; NULL = project inside the kernel): the conditioner projections of all
+ * layers, [B, n_layers * channels, L] from mg_denoiser_cond_project on the same `cond`.  The T steps of a sampling loop
+ * (model/diffusion.py:133-147) call the denoiser with the SAME cond, and conditioner_projection(cond)
+ * (model/blocks.py:266) does not depend on x_t or t: projected once per loop instead of once per step, 11 % of a step's
+ * multiply-adds leave the loop.  Results are bit-identical to cproj == NULL (the kernel forms
+ * fl(fl(W_c cond + b_c) + fl(x + step)) either way). */
 int mg_denoiser_psample(const mg_denoiser_dims *d, const float *packed, const float *x_t, const int64_t *t,
                         const float *cond, const float *spk, const float *coef1, const float *coef2,
                         const float *logvar, int n_steps, const float *noise, unsigned long long seed,
-                        unsigned long long noise_stream, int clip, float *x_prev, float *x0_out, float *workspace,
-                        size_t workspace_floats, int B, int L, int mode, void *stream);
+                        unsigned long long noise_stream, int clip, float *x_prev, float *x0_out, const float *cproj,
+                        float *workspace, size_t workspace_floats, int B, int L, int mode, void *stream);
+/* cproj[b, l * channels + c, :] = conditioner_projection_l(cond[b])[c, :] (model/blocks.py:251,266: Conv1d(H, C, 1) with
+ * bias) for every residual layer l, as one [n_layers * channels, H] x [H, B * L] product.  `packed` must have been built
+ * with MG_DEN_P16 (channels == cond_channels == 256). */
+int mg_denoiser_cond_project(const mg_denoiser_dims *d, const float *packed, const float *cond, float *cproj, int B,
+                             int L, void *stream);
 /* Both generator forwards of a GAN training step (train.py:133 and :153 -- same weights, different t / noise) as ONE
  * launch of 64-frame tiles: problem A (x_tA, tA -> outA; nothing kept) is the D phase's no-grad forward, problem B
  * (x_tB, tB -> outB) the G phase's: its layer activations land in wsB exactly as mg_denoiser_fwd(MG_FWD_SAVE) leaves

@@ -289,6 +289,10 @@ extern "C" int mg_denoiser_pack(const mg_denoiser_dims *d, const float *const *w
             pack(lw[3], pp + o.p_wc, C, H, 1, MG_PACK_PLAIN16);
             pack(lw[0], pp + o.p_w3, 2 * C, C, 3, MG_PACK_GATE16);
             pack(lw[5], pp + o.p_wo, 2 * C, C, 1, MG_PACK_PLAIN16);
+            // the [NL * C, H] matrix of all conditioner projections: 32-row blocks are the outermost index of a pack,
+            // so the layers' own packs, one behind the other, ARE its pack (C is a multiple of the 128-row tile)
+            pack(lw[3], o.wc_all + (size_t)l * mg_conv_packed_floats(C, H, 1, MG_PACK_PLAIN), C, H, 1, MG_PACK_PLAIN);
+            copy(o.bc_all + (size_t)l * C, lw[4], C);
         }
     }
     if (rc != MG_OK) return rc;
@@ -472,6 +476,7 @@ struct PostSample {
     unsigned long long seed, noise_stream;
     float *x0_out;                         // optional pre-clamp x_0
     int n_steps, clip;
+    const float *cproj;                    // optional precomputed conditioner projections (mg_denoiser_cond_project)
 };
 
 // ---- host side of the persistent kernels' failure reporting and slot accounting (declared in denoiser_common.h)
@@ -574,14 +579,29 @@ extern "C" int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, c
 extern "C" int mg_denoiser_psample(const mg_denoiser_dims *d, const float *packed, const float *x_t, const int64_t *t,
                                    const float *cond, const float *spk, const float *coef1, const float *coef2,
                                    const float *logvar, int n_steps, const float *noise, unsigned long long seed,
-                                   unsigned long long noise_stream, int clip, float *x_prev, float *x0_out, float *ws,
-                                   size_t ws_floats, int B, int L, int mode, void *stream)
+                                   unsigned long long noise_stream, int clip, float *x_prev, float *x0_out,
+                                   const float *cproj, float *ws, size_t ws_floats, int B, int L, int mode, void *stream)
 {
     if (!coef1 || !coef2 || !logvar || n_steps <= 0 || !x_prev) return MG_ERR_ARG;
     if (mode & MG_FWD_SAVE) return MG_ERR_ARG;
     if (x_prev == x_t) return MG_ERR_ARG;   // the posterior reads x_t after other tiles have written x_prev
-    const PostSample ps{coef1, coef2, logvar, noise, seed, noise_stream, x0_out, n_steps, clip};
+    if (cproj && !(mode & MG_FWD_P16)) return MG_ERR_ARG;   // the projections come from the inference packs
+    const PostSample ps{coef1, coef2, logvar, noise, seed, noise_stream, x0_out, n_steps, clip, cproj};
     return denoiser_forward(d, packed, x_t, t, cond, spk, x_prev, ws, ws_floats, B, L, mode, &ps, stream);
+}
+
+// Wc_l cond + bc_l for all layers as one GEMM: [NL * C, H] x [H, B * L] -> cproj [B, NL * C, L]
+extern "C" int mg_denoiser_cond_project(const mg_denoiser_dims *d, const float *packed, const float *cond, float *cproj, int B,
+                                        int L, void *stream)
+{
+    MG_TRY(den_check(d));
+    if (!packed || !cond || !cproj) return MG_ERR_ARG;
+    if (B <= 0 || L <= 0 || d->channels % 128) return MG_ERR_SHAPE;
+    const DenLayout o = den_layout(d, MG_DEN_P16);
+    const int C = d->channels, H = d->cond_channels, NL = d->n_layers;
+    ConvShape s{B, H, L, L, 1, 1, 0, NL * C, 0, 0};
+    EpiBiasAct::Params ep{cproj, packed + o.bc_all, nullptr, 1.f, NL * C, MG_ACT_NONE, 0, 0, nullptr, 0.f};
+    return conv_launch<EpiBiasAct>(s, cond, nullptr, packed + o.wc_all, ep, (hipStream_t)stream);
 }
 
 extern "C" int mg_denoiser_persist_status(const mg_denoiser_dims *d, const float *ws, int B, int L, unsigned *host_out4,
@@ -705,6 +725,7 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
         a.out2 = nullptr;
         a.x_t = x_t;
         a.cond = cond;
+        a.cproj = post ? post->cproj : nullptr;
         a.in_w = packed + o.in_w;
         a.in_b = packed + o.in_b;
         a.layers = lay0;
@@ -975,6 +996,7 @@ extern "C" int mg_denoiser_fwd_pair(const mg_denoiser_dims *d, const float *pack
     a.dvec2 = wsB + wB.dvec;
     a.b_split = Bh;
     a.cond = cond;
+    a.cproj = nullptr;
     a.cond2 = condB;
     a.in_w = packed + o.in_w;
     a.in_b = packed + o.in_b;

@@ -27,6 +27,9 @@ struct DenLayout {
     size_t slayers, slayer_stride, sl_wc, sl_w3, sl_wo;
     // 16x16x4-MFMA packs (denoiser_persist16.h), present when flags & MG_DEN_P16
     size_t in_w16, skip_w16, out_w16, p16layers, p16layer_stride, p_wc, p_w3, p_wo;
+    // ... and with them (inference packs): every layer's conditioner projection as ONE [NL * C, H] forward GEMM with its
+    // biases (mg_denoiser_cond_project: the x_t-independent part of all GEMM 1s of a sampling loop)
+    size_t wc_all, bc_all;
     size_t jobs;   // scratch slice for the pack job table (mg_denoiser_pack)
     size_t total;
 };
@@ -108,6 +111,7 @@ static inline DenLayout den_layout(const mg_denoiser_dims *d, int flags)
         p += r * NL;
     }
     o.in_w16 = o.skip_w16 = o.out_w16 = o.p16layers = o.p16layer_stride = o.p_wc = o.p_w3 = o.p_wo = 0;
+    o.wc_all = o.bc_all = 0;
     if (flags & MG_DEN_P16) {
         o.in_w16 = take(mg_conv_packed_floats(C, M, 1, MG_PACK_PLAIN16));
         o.skip_w16 = take(mg_conv_packed_floats(C, C, 1, MG_PACK_PLAIN16));
@@ -124,6 +128,8 @@ static inline DenLayout den_layout(const mg_denoiser_dims *d, int flags)
         o.p_wo = ptake(mg_conv_packed_floats(2 * C, C, 1, MG_PACK_PLAIN16));
         o.p16layer_stride = r;
         p += r * NL;
+        o.wc_all = take((size_t)NL * mg_conv_packed_floats(C, H, 1, MG_PACK_PLAIN));   // C % 128 == 0: row blocks concatenate
+        o.bc_all = take((size_t)NL * C);
     }
     // reserved for the job table of mg_denoiser_pack (768 entries x 96 B, 16-byte aligned)
     p = mg_align_up(p, 64);

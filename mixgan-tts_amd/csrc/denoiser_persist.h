@@ -44,6 +44,7 @@ typedef __attribute__((address_space(1))) unsigned dp_gu32;
 struct PersistArgs {
     const float *x_t;    // [B, M, L]
     const float *cond;   // [B, 256, L]
+    const float *cproj;  // optional [B, NL * 256, L]: Wc_l cond + bc_l of every layer, precomputed (mg_denoiser_cond_project)
     const float *in_w, *in_b;             // packed PLAIN [256 rows, K = 96], [256]
     const float *layers;                  // first layer record
     size_t layer_stride, l_wc, l_w3, l_wo, l_bc, l_b3, l_bo;
@@ -292,7 +293,9 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
     // ---------------------------------------------------------------- stage the cond tile (once) and the x_t tile
     {
         const float *cb = (second ? a.cond2 : a.cond) + (size_t)b * RB_C * L;
-        if (VEC4) {
+        if (a.cproj) {
+            // the conditioner enters only through its precomputed projections: no tile to stage
+        } else if (VEC4) {
 #pragma unroll
             for (int k = 0; k < 64 * NT / NTHR; ++k) {   // 256 rows x NT/4 float4 (frames l0 .. l0+NT-1)
                 const int idx = tid + k * NTHR;
@@ -386,21 +389,47 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
         stamp_row = l + 1;
         DP_STAMP(0);
 
-        // ------------------------------------------------------------ GEMM 1: h = Wc cond + bc + x + (Wd s [+ Wp spk])
+        // ------------------------------------------------------------ GEMM 1: h = (Wc cond + bc) + (x + (Wd s [+ Wp spk]))
+        // The first bracket does not depend on x_t: inside a T-step sampling loop it is the same in every step, and the
+        // caller may hand it over precomputed for all layers (a.cproj, mg_denoiser_cond_project: one GEMM per loop
+        // instead of one per layer and step).  Both ways evaluate fl(fl(sum_k + bc) + fl(x + vec)) with the sum over k
+        // accumulated from zero in channel order -- bit-identical results.
         f32x16 acc1[MB][NNB];
+        if (a.cproj) {
+            const float *cp = a.cproj + ((size_t)b * a.NL + l) * RB_C * L;
 #pragma unroll
-        for (int i = 0; i < MB; ++i)
+            for (int i = 0; i < MB; ++i)
 #pragma unroll
-            for (int j = 0; j < NNB; ++j)
+                for (int j = 0; j < NNB; ++j) {
+                    const int fcj = min(l0 + 32 * j + c32, L - 1);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc1[i][j][r] = st[i][j][r] + (lp[a.l_bc + row_of(i, r)] + hv[row_of(i, r)]);
-        {
+                    for (int r = 0; r < 16; ++r) acc1[i][j][r] = cp[(size_t)row_of(i, r) * L + fcj];
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NNB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
             const f32x4 *wc = reinterpret_cast<const f32x4 *>(lp + a.l_wc);
             const f32x4 *ap[MB];
 #pragma unroll
             for (int i = 0; i < MB; ++i) ap[i] = wc + (size_t)(MB * w + i) * 32 * 64 + lane;
             dp_mfma_loop<MB, NNB, NC, DpIterK1>(acc1, ap, condT + c32 * 8 + hh * 4);
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NNB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc1[i][j][r] += lp[a.l_bc + row_of(i, r)];
         }
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NNB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[i][j][r] += st[i][j][r] + hv[row_of(i, r)];
         DP_STAMP(1);
         // GEMM 2's accumulators start at the conv bias: these loads fly during the barrier and the h write-back.
         // acc2[p][0] = gate rows, acc2[p][1] = filter rows of channels 32*(MB*w + p) .. +31

@@ -246,14 +246,35 @@ class Denoiser(nn.Module):
         self.last_ws = ws_b
         return out_a, out_b, ws_b
 
+    def has_cond_projection(self, packed=None):
+        """True when the packs hold the all-layer conditioner projection (the fp32 inference packs, C = H = 256)."""
+        packed = self.packed_weights() if packed is None else packed
+        return (self.precision != "bf16x3" and self._packed_key is not None and bool(self._packed_key[0] & 4)
+                and packed is self._packed)
+
+    def cond_projection(self, cond, out=None, packed=None):
+        """conditioner_projection(cond) of every residual layer (model/blocks.py:251,266) as one product:
+        cond [B,H,L] -> [B, n_layers * C, L].  It depends on neither x_t nor t, so a T-step sampling loop
+        (model/diffusion.py:133-147) computes it once and hands it to each p_sample(cproj=...)."""
+        packed = self.packed_weights() if packed is None else packed
+        if not self.has_cond_projection(packed):
+            raise _lib.MixganHipError("cond_projection needs the fp32 inference packs (channels = cond channels = 256)")
+        B, _, L = cond.shape
+        if out is None:
+            out = torch.empty(B, self._dims.n_layers * self._dims.channels, L, device=cond.device, dtype=torch.float32)
+        check(_lib.lib().mg_denoiser_cond_project(ctypes.byref(self._dims), fptr(packed), fptr(cond), fptr(out), B, L,
+                                                  stream_ptr()))
+        return out
+
     def p_sample(self, x_t, t, cond, spk, coef1, coef2, logvar, noise=None, clip=True, out=None, x0_out=None,
-                 packed=None, ws=None):
+                 packed=None, ws=None, cproj=None):
         """One reverse step (model/diffusion.py:121-129) as one library call: x_0 = forward(x_t); clamp; posterior mean
         + sigma * noise.  x_t [B,M,L], cond [B,H,L]; coef1 / coef2 / logvar: the diffusion's posterior_mean_coef1 / 2 and
         posterior_log_variance_clipped buffers.  noise None = drawn in the kernel: Philox keyed by a seed taken once
         from torch's generator (so torch.manual_seed reproduces a run) mixed with the rank and device; the counter is
         (this workspace's process-wide number, launches on it so far -- kept on the device), fresh on every call, every
-        shape, every re-allocated workspace and every replay of every captured graph.
+        shape, every re-allocated workspace and every replay of every captured graph.  cproj: cond_projection(cond),
+        computed once per sampling loop (same result bit for bit, 11 % fewer multiply-adds per step).
         Returns x_{t-1} [B,M,L] (a new tensor or `out`, never x_t itself)."""
         B, M, L = x_t.shape
         raise_if_failed((self,))
@@ -271,8 +292,8 @@ class Denoiser(nn.Module):
         check(_lib.lib().mg_denoiser_psample(
             ctypes.byref(self._dims), fptr(packed), fptr(x_t), iptr(t, torch.int64), fptr(cond),
             fptr(spk, not self.multi_speaker), fptr(coef1), fptr(coef2), fptr(logvar), coef1.numel(), fptr(noise, True),
-            self._rng_seed, self._noise_stream_of(ws), int(bool(clip)), fptr(out), fptr(x0_out, True), fptr(ws),
-            ws.numel(), B, L, mode, stream_ptr()))
+            self._rng_seed, self._noise_stream_of(ws), int(bool(clip)), fptr(out), fptr(x0_out, True),
+            fptr(cproj, True), fptr(ws), ws.numel(), B, L, mode, stream_ptr()))
         return out
 
     @staticmethod

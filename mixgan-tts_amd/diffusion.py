@@ -120,11 +120,35 @@ class GaussianDiffusion(nn.Module):
         noise = self._bml(self._randn((B, 1, M, L), x.device)) if self.noise_fn is not None else None
         return self._p_sample_bml(x, t.contiguous(), cond.contiguous(), spk_emb, noise, clip_denoised)[:, None]
 
-    def _p_sample_bml(self, x, t, cond, spk, noise, clip=True, out=None, packed=None, ws=None):
+    def _p_sample_bml(self, x, t, cond, spk, noise, clip=True, out=None, packed=None, ws=None, cproj=None):
         """Denoiser.forward + clamp + posterior sample on [B,M,L] tensors as ONE library call (one kernel launch on the
-        fp32 inference path).  noise None: N(0,1) drawn inside the kernel."""
+        fp32 inference path).  noise None: N(0,1) drawn inside the kernel.  cproj: _loop_cond_projection(cond)."""
         return self.denoise_fn.p_sample(x, t, cond, spk, self.posterior_mean_coef1, self.posterior_mean_coef2,
-                                        self.posterior_log_variance_clipped, noise, clip, out, None, packed, ws)
+                                        self.posterior_log_variance_clipped, noise, clip, out, None, packed, ws, cproj)
+
+    # The T steps of a sampling loop (model/diffusion.py:133-147) see the same conditioner, and each residual layer's
+    # conditioner_projection(cond) (model/blocks.py:266) depends on neither x_t nor t: it is computed once per loop and
+    # read by every step (bit-identical results; MG_COND_PREPROJECT=0 keeps it inside each step).
+    cond_preproject = True
+
+    def _preprojects(self, packed):
+        return (self.cond_preproject and self.num_timesteps >= 2 and os.environ.get("MG_COND_PREPROJECT", "1") != "0"
+                and self.denoise_fn.has_cond_projection(packed))
+
+    def _loop_cond_projection(self, cond, packed, out=None):
+        den = self.denoise_fn
+        if not self._preprojects(packed):
+            return None
+        if out is None:
+            B, _, L = cond.shape
+            key = (B, L, cond.device)
+            if self._cproj_buf is None or self._cproj_buf[0] != key:
+                self._cproj_buf = (key, torch.empty(B, den._dims.n_layers * den._dims.channels, L, device=cond.device,
+                                                    dtype=torch.float32))
+            out = self._cproj_buf[1]
+        return den.cond_projection(cond, out, packed)
+
+    _cproj_buf = None
 
     @torch.no_grad()
     def sampling(self, noise=None, keep_trace=True, use_graph=False, _final_keep=None):
@@ -147,10 +171,12 @@ class GaussianDiffusion(nn.Module):
         packed = den.packed_weights()
         x = self._bml(self._randn((B, 1, M, L), dev) if noise is None else noise)
         xs = [x] if keep_trace else None
+        cond = cond.contiguous()
+        cproj = self._loop_cond_projection(cond, packed)
         for i in reversed(range(T)):
             t = torch.full((B,), i, device=dev, dtype=torch.long)
             nz = self._bml(self._randn((B, 1, M, L), dev)) if self.noise_fn is not None else None
-            x = self._p_sample_bml(x, t, cond, self.spk_emb, nz, True, packed=packed)
+            x = self._p_sample_bml(x, t, cond, self.spk_emb, nz, True, packed=packed, cproj=cproj)
             if keep_trace:
                 xs.append(x)
         outs = xs if keep_trace else [x]
@@ -184,7 +210,9 @@ class GaussianDiffusion(nn.Module):
                   "cond": torch.empty_like(cond), "spk": None if spk is None else torch.empty_like(spk),
                   "ts": [torch.full((B,), i, device=dev, dtype=torch.long) for i in range(T)],
                   # the graph bakes in raw pointers: it owns its workspace and holds the packed weights it captured
-                  "ws": den.new_workspace(B, L, False, dev), "packed": packed}
+                  "ws": den.new_workspace(B, L, False, dev), "packed": packed, "cproj": None}
+            if self._preprojects(packed):
+                st["cproj"] = torch.empty(B, den._dims.n_layers * den._dims.channels, L, device=dev)
             st["cond"].copy_(cond)
             if spk is not None:
                 st["spk"].copy_(spk)
@@ -192,9 +220,10 @@ class GaussianDiffusion(nn.Module):
 
             def loop():
                 cur = 0
+                cproj = None if st["cproj"] is None else self._loop_cond_projection(st["cond"], packed, st["cproj"])
                 for i in reversed(range(T)):
                     self._p_sample_bml(st["x"][cur], st["ts"][i], st["cond"], st["spk"], None, True,
-                                       out=st["x"][cur ^ 1], packed=packed, ws=st["ws"])
+                                       out=st["x"][cur ^ 1], packed=packed, ws=st["ws"], cproj=cproj)
                     cur ^= 1
                 return cur
 

@@ -1,0 +1,137 @@
+"""The x_t-independent conditioner projections of a sampling loop, hoisted out of its steps (mg_denoiser_cond_project +
+mg_denoiser_psample's cproj): conditioner_projection(cond) of model/blocks.py:251,266 for all residual layers at once,
+and p_sample reading it instead of projecting inside the kernel -- the same x_{t-1} bit for bit, on every tile width."""
+import pytest
+import torch
+
+from helpers import golden, T, seeded, assert_close, hot_path_configs, write_stats, load_seeded, Tape
+from oracle import refmath as R, schedule as S
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def mg():
+    import mixgan_tts_amd as m
+    assert torch.cuda.is_available()
+    return m
+
+
+def _diffusion(mg, manifest, tmp_path, ms=False):
+    e = golden("elementwise")
+    stats = write_stats(tmp_path, e["spec_min"], e["spec_max"])
+    gd = mg.GaussianDiffusion(*hot_path_configs("naive", 4, multi_speaker=ms, stats_dir=stats))
+    name = "diffusion_naive_ms%d" % int(ms)
+    load_seeded(gd, manifest, name, 31)
+    W, _ = seeded(manifest, name, 31)
+    return gd.cuda().eval(), W
+
+
+def _pin_width(monkeypatch, nt):
+    monkeypatch.setenv("MG_PERSIST_NT", str(16 if nt in (116, 216) else nt))
+    if nt == 116:
+        monkeypatch.setenv("MG_PERSIST_TEAM", "0")
+    elif nt == 216:
+        monkeypatch.setenv("MG_PERSIST_TEAM", "2")
+    else:
+        monkeypatch.delenv("MG_PERSIST_TEAM", raising=False)
+
+
+@pytest.mark.parametrize("B,L", [(2, 200), (1, 77), (3, 1000), (1, 1)])
+def test_cond_projection_matches_every_layers_conv(mg, manifest, tmp_path, B, L):
+    gd, _ = _diffusion(mg, manifest, tmp_path)
+    den = gd.denoise_fn
+    cond = torch.randn(B, 256, L, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    got = den.cond_projection(cond)
+    C = den._dims.channels
+    assert got.shape == (B, den._dims.n_layers * C, L)
+    for l, layer in enumerate(den.residual_layers):
+        conv = layer.conditioner_projection.conv
+        ref = torch.nn.functional.conv1d(cond.double(), conv.weight.double(), conv.bias.double())
+        assert_close(got[:, l * C:(l + 1) * C].cpu(), ref.float().cpu(), TOL, "layer %d" % l)
+
+
+@pytest.mark.parametrize("nt", [16, 216, 116, 32, 64, 328])
+@pytest.mark.parametrize("ms", [False, True])
+def test_p_sample_reading_the_projection_is_bitwise_the_same(mg, manifest, tmp_path, monkeypatch, ms, nt):
+    _pin_width(monkeypatch, nt)
+    gd, W = _diffusion(mg, manifest, tmp_path, ms)
+    den = gd.denoise_fn
+    buf = {k: T(v) for k, v in S.diffusion_buffers(S.beta_schedule("vpsde", 4, 0.1, 40, 0.008)).items()}
+    gen = torch.Generator().manual_seed(17)
+    for B, L in [(1, 200), (2, 129), (3, 333), (1, 1000), (4, 64)]:
+        x = torch.randn(B, 80, L, generator=gen)
+        cond = torch.randn(B, 256, L, generator=gen)
+        spk = torch.randn(B, 256, generator=gen) if ms else None
+        nz = torch.randn(B, 80, L, generator=gen)
+        t = torch.tensor([3, 0, 2, 1][:B])
+        xd, cd, nd, td = x.cuda(), cond.cuda(), nz.cuda(), t.cuda()
+        sd = None if spk is None else spk.cuda()
+        cproj = den.cond_projection(cd)
+        a = gd._p_sample_bml(xd, td, cd, sd, nd)
+        b = gd._p_sample_bml(xd, td, cd, sd, nd, cproj=cproj)
+        assert torch.equal(a, b), "B=%d L=%d: %g" % (B, L, (a - b).abs().max().item())
+        if L <= 333:
+            ref = R.p_sample(W, buf, x[:, None], t, cond, spk, nz[:, None], clip=True)
+            assert_close(b.cpu()[:, None], ref, TOL, "p_sample with projection B=%d L=%d" % (B, L))
+    den.check(sync=True)
+
+
+def test_sampling_loop_same_with_and_without_hoisting(mg, manifest, tmp_path, monkeypatch):
+    gd, _ = _diffusion(mg, manifest, tmp_path)
+    B, L = 2, 300
+    gen = torch.Generator().manual_seed(23)
+    gd.cond = torch.randn(B, 256, L, generator=gen).cuda()
+    gd.spk_emb = None
+    start = torch.randn(B, 1, 80, L, generator=gen)
+    draws = [torch.randn(B, 1, 80, L, generator=gen).numpy() for _ in range(4)]
+    outs = []
+    for hoist in ("1", "0"):
+        monkeypatch.setenv("MG_COND_PREPROJECT", hoist)
+        gd.noise_fn = Tape(list(draws))
+        trace = gd.sampling(noise=start.cuda())
+        assert len(trace) == 5
+        outs.append(trace)
+    gd.noise_fn = None
+    assert gd._cproj_buf is not None and gd._cproj_buf[1].shape == (B, 20 * 256, L)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_graphed_sampling_loop_projects_inside_the_graph(mg, manifest, tmp_path):
+    """The captured loop recomputes the projections from the static conditioner buffer on every replay: a second replay
+    with another conditioner must follow it (zero posterior noise is not available in-graph, so compare t = 0 ...
+    instead: replay twice with the same inputs and different ones, and check against the eager loop's mean path)."""
+    gd, _ = _diffusion(mg, manifest, tmp_path)
+    B, L = 2, 160
+    gen = torch.Generator().manual_seed(29)
+    start = torch.randn(B, 1, 80, L, generator=gen).cuda()
+    c1 = torch.randn(B, 256, L, generator=gen).cuda()
+    c2 = torch.randn(B, 256, L, generator=gen).cuda()
+    gd.spk_emb = None
+    # the last step (t = 0) adds no noise, and the steps before it only perturb x_1: with the clamp to [-1, 1] the final
+    # mel is a function of (x_1, cond); a replay that kept the FIRST conditioner's projections would not follow c2
+    gd.cond = c1
+    a1 = gd.sampling(noise=start.clone(), keep_trace=False, use_graph=True)[-1]
+    assert gd._graph["cproj"] is not None
+    p1 = gd._graph["cproj"].clone()
+    gd.cond = c2
+    a2 = gd.sampling(noise=start.clone(), keep_trace=False, use_graph=True)[-1]
+    p2 = gd._graph["cproj"]
+    assert torch.isfinite(a1).all() and torch.isfinite(a2).all()
+    assert torch.equal(p1, gd.denoise_fn.cond_projection(c1)) and torch.equal(p2, gd.denoise_fn.cond_projection(c2))
+    assert not torch.equal(a1, a2)
+
+
+def test_projection_needs_the_inference_packs(mg, manifest, tmp_path):
+    gd, _ = _diffusion(mg, manifest, tmp_path)
+    den = gd.denoise_fn
+    packed = den.packed_weights(with_backward=True)
+    assert not den.has_cond_projection(packed)
+    with pytest.raises(mg._lib.MixganHipError):
+        den.cond_projection(torch.randn(1, 256, 64, device="cuda"), packed=packed)
+    with pytest.raises(mg._lib.MixganHipError):          # the library refuses cproj without MG_FWD_P16 packs as well
+        x = torch.randn(1, 80, 64, device="cuda")
+        gd._p_sample_bml(x, torch.zeros(1, dtype=torch.long, device="cuda"), torch.randn(1, 256, 64, device="cuda"), None,
+                         torch.zeros_like(x), packed=packed, cproj=torch.zeros(1, 5120, 64, device="cuda"))
