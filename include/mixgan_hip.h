@@ -237,17 +237,17 @@ int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, const float 
  * never walk the same stream; ranks use different seeds.  x_prev [B, M, L] must not alias x_t; x0_out (optional)
  * receives the pre-clamp x_0.  On the fp32 inference path this is ONE kernel launch.
  *
- * cproj (optional, MG_FWD_P16 packs only; NULL = project inside the kernel): the conditioner projections of all
- * layers, [B, n_layers * channels, L] from mg_denoiser_cond_project on the same `cond`.  The T steps of a sampling loop
- * (model/diffusion.py:133-147) call the denoiser with the SAME cond, and conditioner_projection(cond)
- * (model/blocks.py:266) does not depend on x_t or t: projected once per loop instead of once per step, 11 % of a step's
- * multiply-adds leave the loop.  Results are bit-identical to cproj == NULL (the kernel forms
- * fl(fl(W_c cond + b_c) + fl(x + step)) either way). */
+ * cproj / cproj_out (optional, fp32 MG_FWD_P16 packs only, at most one of them): the conditioner projections of all
+ * layers, [B, n_layers * channels, L].  The T steps of a sampling loop (model/diffusion.py:133-147) call the denoiser
+ * with the SAME cond, and conditioner_projection(cond) (model/blocks.py:266) depends on neither x_t nor t: the first
+ * step of a loop passes cproj_out and leaves what it computed there, the steps behind it pass that buffer as cproj and
+ * skip the projections -- 11 % of a step's multiply-adds.  (mg_denoiser_cond_project fills the same buffer without a
+ * step.)  Results are bit-identical to both NULL: the kernel forms fl(fl(W_c cond + b_c) + fl(x + step)) either way. */
 int mg_denoiser_psample(const mg_denoiser_dims *d, const float *packed, const float *x_t, const int64_t *t,
                         const float *cond, const float *spk, const float *coef1, const float *coef2,
                         const float *logvar, int n_steps, const float *noise, unsigned long long seed,
                         unsigned long long noise_stream, int clip, float *x_prev, float *x0_out, const float *cproj,
-                        float *workspace, size_t workspace_floats, int B, int L, int mode, void *stream);
+                        float *cproj_out, float *workspace, size_t workspace_floats, int B, int L, int mode, void *stream);
 /* cproj[b, l * channels + c, :] = conditioner_projection_l(cond[b])[c, :] (model/blocks.py:251,266: Conv1d(H, C, 1) with
  * bias) for every residual layer l, as one [n_layers * channels, H] x [H, B * L] product.  `packed` must have been built
  * with MG_DEN_P16 (channels == cond_channels == 256). */

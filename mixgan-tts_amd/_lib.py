@@ -154,8 +154,8 @@ def _declare(L):
         "mg_mish_fwd": (i, [vp, vp, sz, vp]),
         "mg_mish_bwd": (i, [vp, vp, vp, sz, vp]),
         "mg_step_embed": (i, [vp, vp, vp, i, i, vp]),
-        "mg_denoiser_psample": (i, [dp] + [vp] * 8 + [i, vp, ctypes.c_ulonglong, ctypes.c_ulonglong, i, vp, vp, vp, vp, sz,
-                                    i, i, i, vp]),
+        "mg_denoiser_psample": (i, [dp] + [vp] * 8 + [i, vp, ctypes.c_ulonglong, ctypes.c_ulonglong, i, vp, vp, vp, vp, vp,
+                                    sz, i, i, i, vp]),
         "mg_denoiser_cond_project": (i, [dp, vp, vp, vp, i, i, vp]),
         "mg_persist_error": (ctypes.c_uint, [i]),
         "mg_denoiser_persist_status": (i, [dp, vp, i, i, vp, vp]),

@@ -477,6 +477,7 @@ struct PostSample {
     float *x0_out;                         // optional pre-clamp x_0
     int n_steps, clip;
     const float *cproj;                    // optional precomputed conditioner projections (mg_denoiser_cond_project)
+    float *cproj_out;                      // ... or where this launch leaves them for the next ones
 };
 
 // ---- host side of the persistent kernels' failure reporting and slot accounting (declared in denoiser_common.h)
@@ -580,13 +581,16 @@ extern "C" int mg_denoiser_psample(const mg_denoiser_dims *d, const float *packe
                                    const float *cond, const float *spk, const float *coef1, const float *coef2,
                                    const float *logvar, int n_steps, const float *noise, unsigned long long seed,
                                    unsigned long long noise_stream, int clip, float *x_prev, float *x0_out,
-                                   const float *cproj, float *ws, size_t ws_floats, int B, int L, int mode, void *stream)
+                                   const float *cproj, float *cproj_out, float *ws, size_t ws_floats, int B, int L, int mode,
+                                   void *stream)
 {
     if (!coef1 || !coef2 || !logvar || n_steps <= 0 || !x_prev) return MG_ERR_ARG;
     if (mode & MG_FWD_SAVE) return MG_ERR_ARG;
     if (x_prev == x_t) return MG_ERR_ARG;   // the posterior reads x_t after other tiles have written x_prev
-    if (cproj && !(mode & MG_FWD_P16)) return MG_ERR_ARG;   // the projections come from the inference packs
-    const PostSample ps{coef1, coef2, logvar, noise, seed, noise_stream, x0_out, n_steps, clip, cproj};
+    // the projections belong to the fp32 single-launch kernels (the inference packs); reading and writing exclude each other
+    if ((cproj || cproj_out) && (!(mode & MG_FWD_P16) || (mode & MG_FWD_SPLIT))) return MG_ERR_ARG;
+    if (cproj && cproj_out) return MG_ERR_ARG;
+    const PostSample ps{coef1, coef2, logvar, noise, seed, noise_stream, x0_out, n_steps, clip, cproj, cproj_out};
     return denoiser_forward(d, packed, x_t, t, cond, spk, x_prev, ws, ws_floats, B, L, mode, &ps, stream);
 }
 
@@ -652,6 +656,9 @@ static int psample_tail(const PostSample &ps, const float *x0, const float *x_t,
     }
     return MG_OK;
 }
+
+extern "C" int mg_denoiser_cond_project(const mg_denoiser_dims *d, const float *packed, const float *cond, float *cproj, int B,
+                                        int L, void *stream);
 
 static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, const float *x_t, const int64_t *t,
                             const float *cond, const float *spk, float *out, float *ws, size_t ws_floats, int B,
@@ -726,6 +733,7 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
         a.x_t = x_t;
         a.cond = cond;
         a.cproj = post ? post->cproj : nullptr;
+        a.cproj_out = post ? post->cproj_out : nullptr;
         a.in_w = packed + o.in_w;
         a.in_b = packed + o.in_b;
         a.layers = lay0;
@@ -832,6 +840,8 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
         return MG_OK;
     }
     // launch-per-layer path: x_0 first (into `out`), the posterior as one more elementwise launch at the end
+    if (post && post->cproj_out)   // its kernels project per layer: the projections a later launch may read come from the GEMM
+        MG_TRY(mg_denoiser_cond_project(d, packed, cond, post->cproj_out, B, L, stream));
     float *const final_out = out;
     if (post && post->x0_out) out = post->x0_out;   // otherwise x_0 is produced in `out` and overwritten in place
     // input projection + ReLU (model/modules.py:430-431; the second relu is idempotent)
@@ -997,6 +1007,7 @@ extern "C" int mg_denoiser_fwd_pair(const mg_denoiser_dims *d, const float *pack
     a.b_split = Bh;
     a.cond = cond;
     a.cproj = nullptr;
+    a.cproj_out = nullptr;
     a.cond2 = condB;
     a.in_w = packed + o.in_w;
     a.in_b = packed + o.in_b;

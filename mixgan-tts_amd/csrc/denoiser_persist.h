@@ -44,7 +44,9 @@ typedef __attribute__((address_space(1))) unsigned dp_gu32;
 struct PersistArgs {
     const float *x_t;    // [B, M, L]
     const float *cond;   // [B, 256, L]
-    const float *cproj;  // optional [B, NL * 256, L]: Wc_l cond + bc_l of every layer, precomputed (mg_denoiser_cond_project)
+    const float *cproj;  // optional [B, NL * 256, L]: Wc_l cond + bc_l of every layer, precomputed (mg_denoiser_cond_project
+                         // or an earlier launch's cproj_out): GEMM 1 is skipped
+    float *cproj_out;    // optional, same layout (cproj == NULL): this launch stores its GEMM 1 results there
     const float *in_w, *in_b;             // packed PLAIN [256 rows, K = 96], [256]
     const float *layers;                  // first layer record
     size_t layer_stride, l_wc, l_w3, l_wo, l_bc, l_b3, l_bo;
@@ -423,6 +425,19 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
                 for (int j = 0; j < NNB; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc1[i][j][r] += lp[a.l_bc + row_of(i, r)];
+            if (a.cproj_out) {   // the first step of a sampling loop leaves the projections for the steps behind it
+                float *co = a.cproj_out + ((size_t)b * a.NL + l) * RB_C * L;
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NNB; ++j) {
+                        const int fcj = l0 + 32 * j + c32;
+                        if (fcj < L) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) co[(size_t)row_of(i, r) * L + fcj] = acc1[i][j][r];
+                        }
+                    }
+            }
         }
 #pragma unroll
         for (int i = 0; i < MB; ++i)

@@ -196,6 +196,13 @@ __global__ __launch_bounds__(256, 2) void denoiser_persist16_kernel(PersistArgs 
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc1[i][r] += lp[a.l_bc + row_of(i, r)];
+            if (a.cproj_out && f < L) {
+                float *co = a.cproj_out + ((size_t)b * a.NL + l) * RB_C * L + f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) co[(size_t)row_of(i, r) * L] = acc1[i][r];
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)

@@ -263,6 +263,11 @@ __global__ __launch_bounds__(1024 / TEAM, 2) void denoiser_team16_kernel(Persist
             d16_mfma_loop_deep<1, NC, D16IterK1>(acc1, ap, condT + c16 * 16 + g * 4, ringA);   // preloaded a phase ago
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc1[0][r] += lp[a.l_bc + row_of(r)];
+            if (a.cproj_out && f < L) {
+                float *co = a.cproj_out + ((size_t)b * a.NL + l) * RB_C * L + f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) co[(size_t)row_of(r) * L] = acc1[0][r];
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc1[0][r] += XS[0][r] + hv[row_of(r)];   // fl(fl(sum + bc) + fl(x + vec)) either way

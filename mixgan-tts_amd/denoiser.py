@@ -267,14 +267,15 @@ class Denoiser(nn.Module):
         return out
 
     def p_sample(self, x_t, t, cond, spk, coef1, coef2, logvar, noise=None, clip=True, out=None, x0_out=None,
-                 packed=None, ws=None, cproj=None):
+                 packed=None, ws=None, cproj=None, cproj_out=None):
         """One reverse step (model/diffusion.py:121-129) as one library call: x_0 = forward(x_t); clamp; posterior mean
         + sigma * noise.  x_t [B,M,L], cond [B,H,L]; coef1 / coef2 / logvar: the diffusion's posterior_mean_coef1 / 2 and
         posterior_log_variance_clipped buffers.  noise None = drawn in the kernel: Philox keyed by a seed taken once
         from torch's generator (so torch.manual_seed reproduces a run) mixed with the rank and device; the counter is
         (this workspace's process-wide number, launches on it so far -- kept on the device), fresh on every call, every
-        shape, every re-allocated workspace and every replay of every captured graph.  cproj: cond_projection(cond),
-        computed once per sampling loop (same result bit for bit, 11 % fewer multiply-adds per step).
+        shape, every re-allocated workspace and every replay of every captured graph.  cproj_out / cproj: a
+        [B, n_layers * C, L] buffer the first step of a sampling loop fills with its conditioner projections and the
+        following steps read instead of projecting (same result bit for bit, 11 % fewer multiply-adds per step).
         Returns x_{t-1} [B,M,L] (a new tensor or `out`, never x_t itself)."""
         B, M, L = x_t.shape
         raise_if_failed((self,))
@@ -293,7 +294,7 @@ class Denoiser(nn.Module):
             ctypes.byref(self._dims), fptr(packed), fptr(x_t), iptr(t, torch.int64), fptr(cond),
             fptr(spk, not self.multi_speaker), fptr(coef1), fptr(coef2), fptr(logvar), coef1.numel(), fptr(noise, True),
             self._rng_seed, self._noise_stream_of(ws), int(bool(clip)), fptr(out), fptr(x0_out, True),
-            fptr(cproj, True), fptr(ws), ws.numel(), B, L, mode, stream_ptr()))
+            fptr(cproj, True), fptr(cproj_out, True), fptr(ws), ws.numel(), B, L, mode, stream_ptr()))
         return out
 
     @staticmethod

@@ -120,33 +120,39 @@ class GaussianDiffusion(nn.Module):
         noise = self._bml(self._randn((B, 1, M, L), x.device)) if self.noise_fn is not None else None
         return self._p_sample_bml(x, t.contiguous(), cond.contiguous(), spk_emb, noise, clip_denoised)[:, None]
 
-    def _p_sample_bml(self, x, t, cond, spk, noise, clip=True, out=None, packed=None, ws=None, cproj=None):
+    def _p_sample_bml(self, x, t, cond, spk, noise, clip=True, out=None, packed=None, ws=None, cproj=None,
+                      cproj_out=None):
         """Denoiser.forward + clamp + posterior sample on [B,M,L] tensors as ONE library call (one kernel launch on the
-        fp32 inference path).  noise None: N(0,1) drawn inside the kernel.  cproj: _loop_cond_projection(cond)."""
+        fp32 inference path).  noise None: N(0,1) drawn inside the kernel.  cproj_out / cproj: _loop_cond_buffer(), written
+        by the first step of a sampling loop and read by the others."""
         return self.denoise_fn.p_sample(x, t, cond, spk, self.posterior_mean_coef1, self.posterior_mean_coef2,
-                                        self.posterior_log_variance_clipped, noise, clip, out, None, packed, ws, cproj)
+                                        self.posterior_log_variance_clipped, noise, clip, out, None, packed, ws, cproj,
+                                        cproj_out)
 
     # The T steps of a sampling loop (model/diffusion.py:133-147) see the same conditioner, and each residual layer's
-    # conditioner_projection(cond) (model/blocks.py:266) depends on neither x_t nor t: it is computed once per loop and
-    # read by every step (bit-identical results; MG_COND_PREPROJECT=0 keeps it inside each step).
+    # conditioner_projection(cond) (model/blocks.py:266) depends on neither x_t nor t: the first step of a loop leaves
+    # its projections in a buffer and the steps behind it read them instead of projecting again (bit-identical results;
+    # MG_COND_PREPROJECT=0 or cond_preproject = False: every step projects).
     cond_preproject = True
 
     def _preprojects(self, packed):
         return (self.cond_preproject and self.num_timesteps >= 2 and os.environ.get("MG_COND_PREPROJECT", "1") != "0"
                 and self.denoise_fn.has_cond_projection(packed))
 
-    def _loop_cond_projection(self, cond, packed, out=None):
+    def _loop_cond_buffer(self, cond, packed, new=False):
+        """Where a sampling loop over `cond` keeps its conditioner projections ([B, n_layers * C, L]; None: the loop
+        projects in every step).  Pass it as cproj_out to the loop's first step and as cproj to the others."""
         den = self.denoise_fn
         if not self._preprojects(packed):
             return None
-        if out is None:
-            B, _, L = cond.shape
-            key = (B, L, cond.device)
-            if self._cproj_buf is None or self._cproj_buf[0] != key:
-                self._cproj_buf = (key, torch.empty(B, den._dims.n_layers * den._dims.channels, L, device=cond.device,
-                                                    dtype=torch.float32))
-            out = self._cproj_buf[1]
-        return den.cond_projection(cond, out, packed)
+        B, _, L = cond.shape
+        shape = (B, den._dims.n_layers * den._dims.channels, L)
+        if new:
+            return torch.empty(shape, device=cond.device, dtype=torch.float32)
+        key = (B, L, cond.device, torch.cuda.current_stream(cond.device).cuda_stream)
+        if self._cproj_buf is None or self._cproj_buf[0] != key:
+            self._cproj_buf = (key, torch.empty(shape, device=cond.device, dtype=torch.float32))
+        return self._cproj_buf[1]
 
     _cproj_buf = None
 
@@ -172,11 +178,13 @@ class GaussianDiffusion(nn.Module):
         x = self._bml(self._randn((B, 1, M, L), dev) if noise is None else noise)
         xs = [x] if keep_trace else None
         cond = cond.contiguous()
-        cproj = self._loop_cond_projection(cond, packed)
+        cproj = self._loop_cond_buffer(cond, packed)
         for i in reversed(range(T)):
             t = torch.full((B,), i, device=dev, dtype=torch.long)
             nz = self._bml(self._randn((B, 1, M, L), dev)) if self.noise_fn is not None else None
-            x = self._p_sample_bml(x, t, cond, self.spk_emb, nz, True, packed=packed, cproj=cproj)
+            first = i == T - 1
+            x = self._p_sample_bml(x, t, cond, self.spk_emb, nz, True, packed=packed,
+                                   cproj=None if first else cproj, cproj_out=cproj if first else None)
             if keep_trace:
                 xs.append(x)
         outs = xs if keep_trace else [x]
@@ -210,9 +218,8 @@ class GaussianDiffusion(nn.Module):
                   "cond": torch.empty_like(cond), "spk": None if spk is None else torch.empty_like(spk),
                   "ts": [torch.full((B,), i, device=dev, dtype=torch.long) for i in range(T)],
                   # the graph bakes in raw pointers: it owns its workspace and holds the packed weights it captured
-                  "ws": den.new_workspace(B, L, False, dev), "packed": packed, "cproj": None}
-            if self._preprojects(packed):
-                st["cproj"] = torch.empty(B, den._dims.n_layers * den._dims.channels, L, device=dev)
+                  "ws": den.new_workspace(B, L, False, dev), "packed": packed,
+                  "cproj": self._loop_cond_buffer(cond, packed, new=True)}
             st["cond"].copy_(cond)
             if spk is not None:
                 st["spk"].copy_(spk)
@@ -220,10 +227,11 @@ class GaussianDiffusion(nn.Module):
 
             def loop():
                 cur = 0
-                cproj = None if st["cproj"] is None else self._loop_cond_projection(st["cond"], packed, st["cproj"])
                 for i in reversed(range(T)):
+                    first = i == T - 1
                     self._p_sample_bml(st["x"][cur], st["ts"][i], st["cond"], st["spk"], None, True,
-                                       out=st["x"][cur ^ 1], packed=packed, ws=st["ws"], cproj=cproj)
+                                       out=st["x"][cur ^ 1], packed=packed, ws=st["ws"],
+                                       cproj=None if first else st["cproj"], cproj_out=st["cproj"] if first else None)
                     cur ^= 1
                 return cur
 

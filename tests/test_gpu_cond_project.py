@@ -72,6 +72,11 @@ def test_p_sample_reading_the_projection_is_bitwise_the_same(mg, manifest, tmp_p
         a = gd._p_sample_bml(xd, td, cd, sd, nd)
         b = gd._p_sample_bml(xd, td, cd, sd, nd, cproj=cproj)
         assert torch.equal(a, b), "B=%d L=%d: %g" % (B, L, (a - b).abs().max().item())
+        # ... and a step that leaves its own projections behind: the same x_{t-1}, the same projections as the GEMM
+        left = torch.full_like(cproj, float("nan"))
+        c = gd._p_sample_bml(xd, td, cd, sd, nd, cproj_out=left)
+        assert torch.equal(a, c) and torch.equal(left, cproj), "B=%d L=%d" % (B, L)
+        assert torch.equal(a, gd._p_sample_bml(xd, td, cd, sd, nd, cproj=left))
         if L <= 333:
             ref = R.p_sample(W, buf, x[:, None], t, cond, spk, nz[:, None], clip=True)
             assert_close(b.cpu()[:, None], ref, TOL, "p_sample with projection B=%d L=%d" % (B, L))
@@ -95,8 +100,28 @@ def test_sampling_loop_same_with_and_without_hoisting(mg, manifest, tmp_path, mo
         outs.append(trace)
     gd.noise_fn = None
     assert gd._cproj_buf is not None and gd._cproj_buf[1].shape == (B, 20 * 256, L)
+    assert torch.equal(gd._cproj_buf[1], gd.denoise_fn.cond_projection(gd.cond))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_launch_per_layer_path_fills_the_projections_too(mg, manifest, tmp_path, monkeypatch):
+    """MG_DENOISER_PERSIST=0 (and every shape the single-launch kernels do not take): the step projects per layer as
+    before and the buffer a later step may read is filled by the GEMM."""
+    gd, _ = _diffusion(mg, manifest, tmp_path)
+    den = gd.denoise_fn
+    gen = torch.Generator().manual_seed(31)
+    B, L = 2, 150
+    x, cond, nz = (torch.randn(B, c, L, generator=gen).cuda() for c in (80, 256, 80))
+    t = torch.tensor([2, 1]).cuda()
+    a = gd._p_sample_bml(x, t, cond, None, nz)
+    monkeypatch.setenv("MG_DENOISER_PERSIST", "0")
+    left = torch.full((B, 5120, L), float("nan"), device="cuda")
+    b = gd._p_sample_bml(x, t, cond, None, nz, cproj_out=left)
+    assert torch.equal(left, den.cond_projection(cond))
+    c = gd._p_sample_bml(x, t, cond, None, nz, cproj=left)          # ignored by the per-layer kernels
+    assert torch.equal(b, c)
+    assert_close(b.cpu(), a.cpu(), TOL, "per-layer path")
 
 
 def test_graphed_sampling_loop_projects_inside_the_graph(mg, manifest, tmp_path):
@@ -121,6 +146,7 @@ def test_graphed_sampling_loop_projects_inside_the_graph(mg, manifest, tmp_path)
     p2 = gd._graph["cproj"]
     assert torch.isfinite(a1).all() and torch.isfinite(a2).all()
     assert torch.equal(p1, gd.denoise_fn.cond_projection(c1)) and torch.equal(p2, gd.denoise_fn.cond_projection(c2))
+    assert p2.data_ptr() != gd._loop_cond_buffer(c2, gd.denoise_fn.packed_weights()).data_ptr()   # the graph owns its buffer
     assert not torch.equal(a1, a2)
 
 
