@@ -42,10 +42,12 @@ FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2
 # command), and the line says so in roofline.traffic_source.  Default shape, fp32, single-launch kernel only.
 
 
-def tracked_traffic():
+def tracked_traffic(hoisted=True):
     try:
         with open(os.path.join(ROOT, "profiles", "bench_traffic.json")) as f:
             t = json.load(f)
+        if not hoisted:
+            t = t["projection_in_every_step"]
         return int(t["traffic_bytes_per_launch"]), t["source"]
     except Exception:
         return None, None
@@ -250,7 +252,7 @@ def main():
                              "prices the full reference step in every launch against the wall clock"
                              % (COND_PROJ_FLOP_PER_FRAME, FLOP_PER_FRAME, T, T - 1))
             if single and precision == "fp32" and (B, L) == (B_PER_GPU, L_FRAMES):
-                r["traffic"], r["traffic_source"] = tracked_traffic()
+                r["traffic"], r["traffic_source"] = tracked_traffic(hoisted)
             r.update(extra)
             return r
 
