@@ -163,6 +163,8 @@ def main():
         hoist = hoists(precision) if hoist is None else hoist
         hoist = hoist and den.has_cond_projection(pk)
         cbuf = gd._loop_cond_buffer(cond, pk) if hoist else None
+        loop_ts = gd._loop_ts(B, dev)          # [T, B]: row k = t of step k of a loop = T-1-k
+        state = {"vecs": None}
 
         def step_(i, xin, xout):
             # one library call per step: Denoiser.forward + clamp + posterior sample with in-kernel noise
@@ -170,10 +172,15 @@ def main():
             # over, as back-to-back sampling loops do (model/diffusion.py:133-147); like GaussianDiffusion.sampling, the
             # first step of every loop (t = T-1) projects the conditioner as the reference's every step does and leaves
             # the 20 layers' projections in a buffer, the T-1 steps behind it read them (bit-identical to projecting in
-            # every step).  Every loop recomputes them: nothing is carried over from one loop to the next.
-            first = i % T == 0
-            gd._p_sample_bml(xin, ts[(T - 1 - i) % T], cond, None, None, True, out=xout, packed=pk,
-                             cproj=None if first else cbuf, cproj_out=cbuf if first else None)
+            # every step).  Likewise the step-dependent vectors (step embedding -> MLP -> per-layer projections): a loop
+            # knows its T values of t, so its first step's call computes them for all T steps in one set of launches.
+            # Every loop recomputes both: nothing is carried over from one loop to the next.
+            k = i % T
+            if hoist and k == 0:
+                state["vecs"] = den.step_vectors(loop_ts, None, pk)
+            gd._p_sample_bml(xin, loop_ts[k], cond, None, None, True, out=xout, packed=pk,
+                             cproj=None if k == 0 else cbuf, cproj_out=cbuf if k == 0 else None,
+                             step_vectors=(state["vecs"], k, T) if hoist else None)
 
         cur, nxt = x, 0           # x_{t-1} never aliases x_t: ping-pong between the two buffers
         for i in range(args.warmup):

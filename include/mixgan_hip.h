@@ -237,17 +237,40 @@ int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, const float 
  * never walk the same stream; ranks use different seeds.  x_prev [B, M, L] must not alias x_t; x0_out (optional)
  * receives the pre-clamp x_0.  On the fp32 inference path this is ONE kernel launch.
  *
- * cproj / cproj_out (optional, fp32 MG_FWD_P16 packs only, at most one of them): the conditioner projections of all
- * layers, [B, n_layers * channels, L].  The T steps of a sampling loop (model/diffusion.py:133-147) call the denoiser
- * with the SAME cond, and conditioner_projection(cond) (model/blocks.py:266) depends on neither x_t nor t: the first
- * step of a loop passes cproj_out and leaves what it computed there, the steps behind it pass that buffer as cproj and
- * skip the projections -- 11 % of a step's multiply-adds.  (mg_denoiser_cond_project fills the same buffer without a
- * step.)  Results are bit-identical to both NULL: the kernel forms fl(fl(W_c cond + b_c) + fl(x + step)) either way. */
+ *
+ * loop (optional): what the T steps of one sampling loop (model/diffusion.py:133-147) share -- see mg_sampling_loop.
+ * Results are bit-identical to loop == NULL. */
+typedef struct mg_sampling_loop {
+    /* cproj / cproj_out (fp32 MG_FWD_P16 packs only, at most one of them): the conditioner projections of all layers,
+     * [B, n_layers * channels, L].  The steps of a loop call the denoiser with the SAME cond, and
+     * conditioner_projection(cond) (model/blocks.py:266) depends on neither x_t nor t: the first step passes cproj_out
+     * and leaves what it computed there, the steps behind it pass that buffer as cproj and skip the projections -- 11 %
+     * of a step's multiply-adds.  (mg_denoiser_cond_project fills the same buffer without a step.)  The kernel forms
+     * fl(fl(W_c cond + b_c) + fl(x + step)) either way. */
+    const float *cproj;
+    float *cproj_out;
+    /* step_vectors: mg_denoiser_step_vectors' output for all step_count steps of the loop (a loop knows its t values
+     * in advance); this call is step step_index of them and reads its slice in place instead of launching the step
+     * embedding, its MLP and the per-layer diffusion / speaker projections (model/modules.py:433-435,
+     * model/blocks.py:1159-1163) itself.  `t` must still be this step's t (the posterior reads it). */
+    const float *step_vectors;
+    int step_index, step_count;
+} mg_sampling_loop;
 int mg_denoiser_psample(const mg_denoiser_dims *d, const float *packed, const float *x_t, const int64_t *t,
                         const float *cond, const float *spk, const float *coef1, const float *coef2,
                         const float *logvar, int n_steps, const float *noise, unsigned long long seed,
-                        unsigned long long noise_stream, int clip, float *x_prev, float *x0_out, const float *cproj,
-                        float *cproj_out, float *workspace, size_t workspace_floats, int B, int L, int mode, void *stream);
+                        unsigned long long noise_stream, int clip, float *x_prev, float *x0_out,
+                        const mg_sampling_loop *loop, float *workspace, size_t workspace_floats, int B, int L, int mode,
+                        void *stream);
+/* The step-dependent vectors of Denoiser.forward for n steps at once: t [n, B] (step-major), spk [B, H] (the same
+ * utterances in every step; NULL unless multi_speaker).  For each step: diffusion_embedding(t) -> mlp
+ * (model/modules.py:433-434), then per residual layer diffusion_projection(.) and, multi-speaker,
+ * + speaker_projection(spk) (model/blocks.py:1159-1163).  `vectors`: mg_denoiser_step_vectors_floats(d, n, B) floats,
+ * opaque; pass it to each step's mg_denoiser_psample through mg_sampling_loop.  Same values bit for bit as the vectors
+ * a step computes for itself. */
+size_t mg_denoiser_step_vectors_floats(const mg_denoiser_dims *d, int n, int B);
+int mg_denoiser_step_vectors(const mg_denoiser_dims *d, const float *packed, const int64_t *t, const float *spk,
+                             float *vectors, size_t vectors_floats, int n, int B, void *stream);
 /* cproj[b, l * channels + c, :] = conditioner_projection_l(cond[b])[c, :] (model/blocks.py:251,266: Conv1d(H, C, 1) with
  * bias) for every residual layer l, as one [n_layers * channels, H] x [H, B * L] product.  `packed` must have been built
  * with MG_DEN_P16 (channels == cond_channels == 256). */

@@ -23,7 +23,7 @@ EXPORTS = (
     "mg_loss_sum", "mg_loss_grad", "mg_mel_l1_fwd", "mg_mel_l1_bwd", "mg_attention_fwd", "mg_attention_fwd_f16", "mg_layernorm_cm_fwd",
     "mg_length_regulate_fwd", "mg_length_regulate_bwd", "mg_word_pool_fwd", "mg_word_pool_bwd", "mg_mapping_mask",
     "mg_rel_coef", "mg_resblock_fwd", "mg_gate_bwd", "mg_mish_fwd", "mg_mish_bwd", "mg_step_embed",
-    "mg_denoiser_psample", "mg_denoiser_cond_project", "mg_denoiser_persist_status", "mg_persist_error", "mg_denoiser_fwd_pair",
+    "mg_denoiser_psample", "mg_denoiser_cond_project", "mg_denoiser_step_vectors_floats", "mg_denoiser_step_vectors", "mg_denoiser_persist_status", "mg_persist_error", "mg_denoiser_fwd_pair",
     "mg_grad_norm_scratch_floats", "mg_grad_norm", "mg_adam_flat", "mg_adam_flat_dev",
     "mg_multi_loss_scratch_floats", "mg_multi_loss_fwd", "mg_multi_loss_bwd",
 )
@@ -45,6 +45,12 @@ class LossTerm(ctypes.Structure):
 class DenoiserDims(ctypes.Structure):
     _fields_ = [("n_layers", ctypes.c_int32), ("channels", ctypes.c_int32), ("cond_channels", ctypes.c_int32),
                 ("mel_bins", ctypes.c_int32), ("multi_speaker", ctypes.c_int32)]
+
+
+class SamplingLoop(ctypes.Structure):
+    """mg_sampling_loop (include/mixgan_hip.h): what the steps of one sampling loop share."""
+    _fields_ = [("cproj", ctypes.c_void_p), ("cproj_out", ctypes.c_void_p), ("step_vectors", ctypes.c_void_p),
+                ("step_index", ctypes.c_int32), ("step_count", ctypes.c_int32)]
 
 
 def library_path():
@@ -154,8 +160,10 @@ def _declare(L):
         "mg_mish_fwd": (i, [vp, vp, sz, vp]),
         "mg_mish_bwd": (i, [vp, vp, vp, sz, vp]),
         "mg_step_embed": (i, [vp, vp, vp, i, i, vp]),
-        "mg_denoiser_psample": (i, [dp] + [vp] * 8 + [i, vp, ctypes.c_ulonglong, ctypes.c_ulonglong, i, vp, vp, vp, vp, vp,
-                                    sz, i, i, i, vp]),
+        "mg_denoiser_psample": (i, [dp] + [vp] * 8 + [i, vp, ctypes.c_ulonglong, ctypes.c_ulonglong, i, vp, vp, vp, vp, sz,
+                                    i, i, i, vp]),
+        "mg_denoiser_step_vectors_floats": (sz, [dp, i, i]),
+        "mg_denoiser_step_vectors": (i, [dp, vp, vp, vp, vp, sz, i, i, vp]),
         "mg_denoiser_cond_project": (i, [dp, vp, vp, vp, i, i, vp]),
         "mg_persist_error": (ctypes.c_uint, [i]),
         "mg_denoiser_persist_status": (i, [dp, vp, i, i, vp, vp]),

@@ -478,6 +478,8 @@ struct PostSample {
     int n_steps, clip;
     const float *cproj;                    // optional precomputed conditioner projections (mg_denoiser_cond_project)
     float *cproj_out;                      // ... or where this launch leaves them for the next ones
+    const float *step_vectors;             // optional mg_denoiser_step_vectors output of step_count steps;
+    int step_index, step_count;            //   this launch is step step_index of them
 };
 
 // ---- host side of the persistent kernels' failure reporting and slot accounting (declared in denoiser_common.h)
@@ -548,8 +550,33 @@ extern "C" void mg_debug_persist_stamps(unsigned long long *device_buffer) { g_p
 
 // step embedding -> MLP -> per-layer projections (model/modules.py:433-434, blocks.py:1159): fills ws.emb / h1pre / h1 / s
 // (kept for the backward in a save workspace) and the per-layer vectors dvec [NL][B][C] (hvec: + speaker projection)
+// `rows` = B for one forward; n B for the n steps of a sampling loop at once (t [n][B], the B speaker rows repeating)
+struct StepVecAt {
+    size_t emb, h1pre, h1, s, dvec, hvec, total;
+};
+static inline StepVecAt den_stepvec_layout(const mg_denoiser_dims *d, size_t rows)
+{
+    const size_t C = d->channels, NL = d->n_layers;
+    StepVecAt w;
+    size_t p = 0;
+    auto take = [&](size_t n) {
+        size_t at = p;
+        p += mg_align_up(n, 64);
+        return at;
+    };
+    w.emb = take(rows * C);
+    w.h1pre = take(rows * 4 * C);
+    w.h1 = take(rows * 4 * C);
+    w.s = take(rows * C);
+    w.dvec = take(NL * rows * C);
+    w.hvec = d->multi_speaker ? take(NL * rows * C) : w.dvec;
+    w.total = p;
+    return w;
+}
+
+template <class At>
 static int den_step_vectors(const mg_denoiser_dims *d, const DenLayout &o, const float *packed, const int64_t *t,
-                            const float *spk, float *ws, const DenWs &w, int B, hipStream_t st)
+                            const float *spk, float *ws, const At &w, int B, hipStream_t st, int spk_rows = 0)
 {
     const int C = d->channels, H = d->cond_channels, NL = d->n_layers;
     const float *lay0 = packed + o.layers;
@@ -562,8 +589,28 @@ static int den_step_vectors(const mg_denoiser_dims *d, const DenLayout &o, const
                         C, C, NL, 0, st));
     if (d->multi_speaker)
         MG_TRY(small_linear(lay0 + o.l_wp, (long)o.layer_stride, spk, ws + w.hvec, (long)B * C, ws + w.dvec,
-                            (long)B * C, nullptr, B, C, H, NL, 0, st));
+                            (long)B * C, nullptr, B, C, H, NL, 0, st, spk_rows));
     return MG_OK;
+}
+
+extern "C" size_t mg_denoiser_step_vectors_floats(const mg_denoiser_dims *d, int n, int B)
+{
+    if (den_check(d) != MG_OK || n <= 0 || B <= 0) return 0;
+    return den_stepvec_layout(d, (size_t)n * B).total;
+}
+
+// The step-dependent vectors of Denoiser.forward for the n steps of a sampling loop in one set of launches
+extern "C" int mg_denoiser_step_vectors(const mg_denoiser_dims *d, const float *packed, const int64_t *t, const float *spk,
+                                        float *vectors, size_t vectors_floats, int n, int B, void *stream)
+{
+    MG_TRY(den_check(d));
+    if (!packed || !t || !vectors) return MG_ERR_ARG;
+    if (d->multi_speaker && !spk) return MG_ERR_ARG;
+    if (n <= 0 || B <= 0) return MG_ERR_SHAPE;
+    const StepVecAt w = den_stepvec_layout(d, (size_t)n * B);
+    if (vectors_floats < w.total) return MG_ERR_WORKSPACE;
+    const DenLayout o = den_layout(d, 0);
+    return den_step_vectors(d, o, packed, t, spk, vectors, w, n * B, (hipStream_t)stream, B);
 }
 
 static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, const float *x_t, const int64_t *t,
@@ -581,16 +628,22 @@ extern "C" int mg_denoiser_psample(const mg_denoiser_dims *d, const float *packe
                                    const float *cond, const float *spk, const float *coef1, const float *coef2,
                                    const float *logvar, int n_steps, const float *noise, unsigned long long seed,
                                    unsigned long long noise_stream, int clip, float *x_prev, float *x0_out,
-                                   const float *cproj, float *cproj_out, float *ws, size_t ws_floats, int B, int L, int mode,
+                                   const mg_sampling_loop *loop, float *ws, size_t ws_floats, int B, int L, int mode,
                                    void *stream)
 {
+    const float *cproj = loop ? loop->cproj : nullptr;
+    float *cproj_out = loop ? loop->cproj_out : nullptr;
+    const float *step_vectors = loop ? loop->step_vectors : nullptr;
+    if (step_vectors && (loop->step_count <= 0 || loop->step_index < 0 || loop->step_index >= loop->step_count))
+        return MG_ERR_ARG;
     if (!coef1 || !coef2 || !logvar || n_steps <= 0 || !x_prev) return MG_ERR_ARG;
     if (mode & MG_FWD_SAVE) return MG_ERR_ARG;
     if (x_prev == x_t) return MG_ERR_ARG;   // the posterior reads x_t after other tiles have written x_prev
     // the projections belong to the fp32 single-launch kernels (the inference packs); reading and writing exclude each other
     if ((cproj || cproj_out) && (!(mode & MG_FWD_P16) || (mode & MG_FWD_SPLIT))) return MG_ERR_ARG;
     if (cproj && cproj_out) return MG_ERR_ARG;
-    const PostSample ps{coef1, coef2, logvar, noise, seed, noise_stream, x0_out, n_steps, clip, cproj, cproj_out};
+    const PostSample ps{coef1, coef2, logvar, noise, seed, noise_stream, x0_out, n_steps, clip, cproj, cproj_out, step_vectors,
+                        loop ? loop->step_index : 0, loop ? loop->step_count : 0};
     return denoiser_forward(d, packed, x_t, t, cond, spk, x_prev, ws, ws_floats, B, L, mode, &ps, stream);
 }
 
@@ -679,8 +732,6 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
     const DenLayout o = den_layout(d, (split ? MG_DEN_SPLIT : 0) | (has_p16 ? MG_DEN_P16 : 0));
     const float *lay0 = packed + o.layers;
 
-    MG_TRY(den_step_vectors(d, o, packed, t, spk, ws, w, B, st));
-
     static const bool force_generic = std::getenv("MG_DENOISER_GENERIC") != nullptr;
     const bool fused = !force_generic && C == RB_C && H == RB_C;
     // ---- single-launch forward (denoiser_persist.h): inference in exact fp32; an utterance's chain of 32-frame tiles
@@ -725,7 +776,12 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
     const int tiles_per_b = mg_cdiv(L, nt);
     // a quarter of the chip's workgroup slots (one per CU for the 8-wave forms, two for the 4-wave ones)
     const int chain_cap = (nt == 64 || wide32) ? mg_device_cus() / 4 : mg_device_cus() / 2;
-    if (fused && !no_persist && !split && M <= 96 && NL >= 3 && tiles_per_b <= chain_cap) {
+    const bool persist = fused && !no_persist && !split && M <= 96 && NL >= 3 && tiles_per_b <= chain_cap;
+    // the step-dependent vectors: this launch's own, unless the caller computed them for its whole sampling loop
+    // (mg_denoiser_step_vectors; read in place by the single-launch kernels only)
+    const bool own_vectors = !(persist && post && post->step_vectors);
+    if (own_vectors) MG_TRY(den_step_vectors(d, o, packed, t, spk, ws, w, B, st));
+    if (persist) {
         PersistArgs a;
         a.b_split = 0;
         a.x_t2 = a.hvec2 = a.dvec2 = a.cond2 = nullptr;
@@ -760,6 +816,13 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
         }
         a.hvec = ws + w.hvec;
         a.dvec = ws + w.dvec;
+        a.vec_rows = 0;
+        if (!own_vectors) {
+            const StepVecAt v = den_stepvec_layout(d, (size_t)post->step_count * B);
+            a.hvec = post->step_vectors + v.hvec + (size_t)post->step_index * B * C;
+            a.dvec = post->step_vectors + v.dvec + (size_t)post->step_index * B * C;
+            a.vec_rows = post->step_count * B;
+        }
         a.out = out;
         a.t = t;
         a.coef1 = post ? post->coef1 : nullptr;
@@ -1002,6 +1065,7 @@ extern "C" int mg_denoiser_fwd_pair(const mg_denoiser_dims *d, const float *pack
     a.out2 = outB;
     a.hvec = wsA + wA.hvec;
     a.dvec = wsA + wA.dvec;
+    a.vec_rows = 0;
     a.hvec2 = wsB + wB.hvec;
     a.dvec2 = wsB + wB.dvec;
     a.b_split = Bh;

@@ -271,13 +271,15 @@ static __global__ void step_embed_kernel(const int64_t *__restrict__ t, const fl
 
 __device__ __forceinline__ float mg_softplus(float v) { return v > 20.f ? v : log1pf(expf(v)); }  // F.softplus defaults
 
-// out[z][b][j] = act(sum_i W[z][j][i] * in[b][i]) (+ add[z][b][j]);  one wave per output row j.
+// out[z][b][j] = act(sum_i W[z][j][i] * in[b % in_rows][i]) (+ add[z][b][j]);  one wave per output row j.
 // mish: out = x tanh(softplus(x)) (model/blocks.py:894-896); pre (optional) receives x itself.
+// in_rows < B: the input rows repeat (the speaker embeddings of a batch under the steps of a sampling loop).
 template <int BC>
 __global__ __launch_bounds__(256) void small_linear_kernel(const float *__restrict__ W, long w_zs,
                                                            const float *__restrict__ in, float *__restrict__ out,
                                                            long out_zs, const float *__restrict__ add, long add_zs,
-                                                           float *__restrict__ pre, int B, int N, int K, int mish)
+                                                           float *__restrict__ pre, int B, int N, int K, int mish,
+                                                           int in_rows)
 {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float *__restri
             f32x4 xv[BC];
 #pragma unroll
             for (int b = 0; b < BC; ++b)
-                xv[b] = *reinterpret_cast<const f32x4 *>(in + (size_t)min(b0 + b, B - 1) * K + i);
+                xv[b] = *reinterpret_cast<const f32x4 *>(in + (size_t)(min(b0 + b, B - 1) % in_rows) * K + i);
             // explicit fma chain: the same rounding for every batch slot (a free-form expression lets the
             // SLP vectoriser pick packed mul+add for some slots and fma for others, which breaks bitwise
             // batch independence)
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float *__restri
             const float wv = w[i];
 #pragma unroll
             for (int b = 0; b < BC; ++b)
-                if (b0 + b < B) acc[b] = fmaf(wv, in[(size_t)(b0 + b) * K + i], acc[b]);
+                if (b0 + b < B) acc[b] = fmaf(wv, in[(size_t)((b0 + b) % in_rows) * K + i], acc[b]);
         }
     }
 #pragma unroll
@@ -334,12 +336,13 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float *__restri
 }
 
 static inline int small_linear(const float *W, long w_zs, const float *in, float *out, long out_zs, const float *add,
-                               long add_zs, float *pre, int B, int N, int K, int Z, int mish, hipStream_t st)
+                               long add_zs, float *pre, int B, int N, int K, int Z, int mish, hipStream_t st,
+                               int in_rows = 0)
 {
     constexpr int BC = 8;
     dim3 grid(mg_cdiv(N, 4), mg_cdiv(B, BC), Z);
     hipLaunchKernelGGL(small_linear_kernel<BC>, grid, dim3(256), 0, st, W, w_zs, in, out, out_zs, add, add_zs, pre, B, N,
-                       K, mish);
+                       K, mish, in_rows > 0 ? in_rows : B);
     MG_LAUNCH_CHECK();
     return MG_OK;
 }

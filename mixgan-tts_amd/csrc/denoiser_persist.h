@@ -53,7 +53,8 @@ struct PersistArgs {
     const float *p16layers;               // 16-row packs (denoiser_persist16.h): first layer record, stride, offsets
     size_t p16layer_stride, p_wc, p_w3, p_wo;
     const float *skip_w, *skip_b, *out_w, *out_b;
-    const float *hvec, *dvec;             // [NL][B][256]
+    const float *hvec, *dvec;             // [NL][vec_rows][256], this launch's utterances in rows 0 .. B-1
+    int vec_rows;                         // 0: B (the launch's own vectors); n B: a slice of a sampling loop's n steps
     float *out;                           // [B, M, L]  predicted x_0 (pre-clamp), or x_{t-1} when post != 0
     // fused p_sample tail (post != 0): out = c1[t] clamp(x0) + c2[t] x_t + (t > 0) exp(0.5 lv[t]) noise
     const int64_t *t;                     // [B]
@@ -384,8 +385,9 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
 
     for (int l = 0; l < a.NL; ++l) {
         const float *lp = a.layers + (size_t)l * a.layer_stride;
-        const float *hv = (second ? a.hvec2 : a.hvec) + ((size_t)l * Bp + b) * RB_C;
-        const float *dv = (second ? a.dvec2 : a.dvec) + ((size_t)l * Bp + b) * RB_C;
+        const size_t vrows = a.vec_rows ? (size_t)a.vec_rows : (size_t)Bp;
+        const float *hv = (second ? a.hvec2 : a.hvec) + ((size_t)l * vrows + b) * RB_C;
+        const float *dv = (second ? a.dvec2 : a.dvec) + ((size_t)l * vrows + b) * RB_C;
         const unsigned epoch = launch_no * ((unsigned)a.NL + 1u) + (unsigned)l + 1u;   // never repeats on a workspace
         const int par = l & 1;
         stamp_row = l + 1;

@@ -171,8 +171,9 @@ __global__ __launch_bounds__(256, 2) void denoiser_persist16_kernel(PersistArgs 
     for (int l = 0; l < a.NL; ++l) {
         const float *lp = a.layers + (size_t)l * a.layer_stride;        // biases live in the base layer record
         const float *pp = a.p16layers + (size_t)l * a.p16layer_stride;  // 16-row packs
-        const float *hv = a.hvec + ((size_t)l * a.B + b) * RB_C;
-        const float *dv = a.dvec + ((size_t)l * a.B + b) * RB_C;
+        const size_t vrows = a.vec_rows ? (size_t)a.vec_rows : (size_t)a.B;
+        const float *hv = a.hvec + ((size_t)l * vrows + b) * RB_C;
+        const float *dv = a.dvec + ((size_t)l * vrows + b) * RB_C;
         const unsigned epoch = launch_no * ((unsigned)a.NL + 1u) + (unsigned)l + 1u;
         const int par = l & 1;
 

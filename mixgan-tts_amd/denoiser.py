@@ -266,8 +266,22 @@ class Denoiser(nn.Module):
                                                   stream_ptr()))
         return out
 
+    def step_vectors(self, ts, spk, packed=None):
+        """The step-dependent vectors of forward() -- diffusion_embedding -> mlp (model/modules.py:433-434), every
+        layer's diffusion_projection (+ speaker_projection(spk), model/blocks.py:1159-1163) -- for the n steps of a
+        sampling loop in one set of launches.  ts int64 [n, B]; spk [B, H] | None.  Returns an opaque tensor for
+        p_sample(step_vectors=(tensor, index, n))."""
+        n, B = ts.shape
+        packed = self.packed_weights() if packed is None else packed
+        L = _lib.lib()
+        out = torch.empty(L.mg_denoiser_step_vectors_floats(ctypes.byref(self._dims), n, B), device=ts.device,
+                          dtype=torch.float32)
+        check(L.mg_denoiser_step_vectors(ctypes.byref(self._dims), fptr(packed), iptr(ts, torch.int64),
+                                         fptr(spk, not self.multi_speaker), fptr(out), out.numel(), n, B, stream_ptr()))
+        return out
+
     def p_sample(self, x_t, t, cond, spk, coef1, coef2, logvar, noise=None, clip=True, out=None, x0_out=None,
-                 packed=None, ws=None, cproj=None, cproj_out=None):
+                 packed=None, ws=None, cproj=None, cproj_out=None, step_vectors=None):
         """One reverse step (model/diffusion.py:121-129) as one library call: x_0 = forward(x_t); clamp; posterior mean
         + sigma * noise.  x_t [B,M,L], cond [B,H,L]; coef1 / coef2 / logvar: the diffusion's posterior_mean_coef1 / 2 and
         posterior_log_variance_clipped buffers.  noise None = drawn in the kernel: Philox keyed by a seed taken once
@@ -276,6 +290,7 @@ class Denoiser(nn.Module):
         shape, every re-allocated workspace and every replay of every captured graph.  cproj_out / cproj: a
         [B, n_layers * C, L] buffer the first step of a sampling loop fills with its conditioner projections and the
         following steps read instead of projecting (same result bit for bit, 11 % fewer multiply-adds per step).
+        step_vectors: (self.step_vectors(ts, spk), index of this step in ts, n) -- the loop's vectors computed at once.
         Returns x_{t-1} [B,M,L] (a new tensor or `out`, never x_t itself)."""
         B, M, L = x_t.shape
         raise_if_failed((self,))
@@ -290,11 +305,16 @@ class Denoiser(nn.Module):
         mode = 2 if self.precision == "bf16x3" else 0
         if self._packed_key is not None and (self._packed_key[0] & 4) and packed is self._packed:
             mode |= 4
+        loop = None
+        if cproj is not None or cproj_out is not None or step_vectors is not None:
+            sv = step_vectors or (None, 0, 0)
+            loop = ctypes.byref(_lib.SamplingLoop(fptr(cproj, True).value, fptr(cproj_out, True).value,
+                                                  fptr(sv[0], True).value, int(sv[1]), int(sv[2])))
         check(_lib.lib().mg_denoiser_psample(
             ctypes.byref(self._dims), fptr(packed), fptr(x_t), iptr(t, torch.int64), fptr(cond),
             fptr(spk, not self.multi_speaker), fptr(coef1), fptr(coef2), fptr(logvar), coef1.numel(), fptr(noise, True),
             self._rng_seed, self._noise_stream_of(ws), int(bool(clip)), fptr(out), fptr(x0_out, True),
-            fptr(cproj, True), fptr(cproj_out, True), fptr(ws), ws.numel(), B, L, mode, stream_ptr()))
+            loop, fptr(ws), ws.numel(), B, L, mode, stream_ptr()))
         return out
 
     @staticmethod

@@ -121,13 +121,13 @@ class GaussianDiffusion(nn.Module):
         return self._p_sample_bml(x, t.contiguous(), cond.contiguous(), spk_emb, noise, clip_denoised)[:, None]
 
     def _p_sample_bml(self, x, t, cond, spk, noise, clip=True, out=None, packed=None, ws=None, cproj=None,
-                      cproj_out=None):
+                      cproj_out=None, step_vectors=None):
         """Denoiser.forward + clamp + posterior sample on [B,M,L] tensors as ONE library call (one kernel launch on the
         fp32 inference path).  noise None: N(0,1) drawn inside the kernel.  cproj_out / cproj: _loop_cond_buffer(), written
-        by the first step of a sampling loop and read by the others."""
+        by the first step of a sampling loop and read by the others; step_vectors: (_loop_step_vectors(), index, T)."""
         return self.denoise_fn.p_sample(x, t, cond, spk, self.posterior_mean_coef1, self.posterior_mean_coef2,
                                         self.posterior_log_variance_clipped, noise, clip, out, None, packed, ws, cproj,
-                                        cproj_out)
+                                        cproj_out, step_vectors)
 
     # The T steps of a sampling loop (model/diffusion.py:133-147) see the same conditioner, and each residual layer's
     # conditioner_projection(cond) (model/blocks.py:266) depends on neither x_t nor t: the first step of a loop leaves
@@ -156,6 +156,30 @@ class GaussianDiffusion(nn.Module):
 
     _cproj_buf = None
 
+    def _loop_ts(self, B, dev):
+        """t of the T steps of a sampling loop, in loop order (T-1 .. 0): int64 [T, B]; row i is step i's t."""
+        key = (B, dev, self.num_timesteps)
+        if self._loop_ts_buf is None or self._loop_ts_buf[0] != key:
+            ts = torch.arange(self.num_timesteps - 1, -1, -1, device=dev, dtype=torch.long)[:, None].expand(-1, B)
+            self._loop_ts_buf = (key, ts.contiguous())
+        return self._loop_ts_buf[1]
+
+    _loop_ts_buf = None
+
+    def _loop_step_vectors(self, ts, k, spk, packed, held=None):
+        """A sampling loop knows its t values in advance: the step embedding, its MLP and the per-layer diffusion /
+        speaker projections of many steps in one set of launches instead of one set per step.  Called before step k of
+        the loop with what the previous call returned; returns (vectors, first step, count) covering step k -- a new
+        chunk of up to ~1024 rows (steps x utterances: 50 MB) when k runs past the held one -- or None (each step
+        computes its own)."""
+        if not self._preprojects(packed):
+            return None
+        if held is not None and held[1] <= k < held[1] + held[2]:
+            return held
+        T, B = ts.shape
+        n = min(T - k, max(1, 1024 // B))
+        return (self.denoise_fn.step_vectors(ts[k:k + n], spk, packed), k, n)
+
     @torch.no_grad()
     def sampling(self, noise=None, keep_trace=True, use_graph=False, _final_keep=None):
         """Reverse process from the stashed cond/spk (model/diffusion.py:155-165).
@@ -179,12 +203,15 @@ class GaussianDiffusion(nn.Module):
         xs = [x] if keep_trace else None
         cond = cond.contiguous()
         cproj = self._loop_cond_buffer(cond, packed)
-        for i in reversed(range(T)):
-            t = torch.full((B,), i, device=dev, dtype=torch.long)
+        ts = self._loop_ts(B, dev)
+        vecs = None
+        for k in range(T):                      # step k of the loop: t = T-1-k
+            vecs = self._loop_step_vectors(ts, k, self.spk_emb, packed, vecs)
             nz = self._bml(self._randn((B, 1, M, L), dev)) if self.noise_fn is not None else None
-            first = i == T - 1
-            x = self._p_sample_bml(x, t, cond, self.spk_emb, nz, True, packed=packed,
-                                   cproj=None if first else cproj, cproj_out=cproj if first else None)
+            first = k == 0
+            x = self._p_sample_bml(x, ts[k], cond, self.spk_emb, nz, True, packed=packed,
+                                   cproj=None if first else cproj, cproj_out=cproj if first else None,
+                                   step_vectors=None if vecs is None else (vecs[0], k - vecs[1], vecs[2]))
             if keep_trace:
                 xs.append(x)
         outs = xs if keep_trace else [x]
@@ -216,7 +243,7 @@ class GaussianDiffusion(nn.Module):
             buf = self._buf()
             st = {"key": key, "x": [torch.empty_like(x_start), torch.empty_like(x_start)],
                   "cond": torch.empty_like(cond), "spk": None if spk is None else torch.empty_like(spk),
-                  "ts": [torch.full((B,), i, device=dev, dtype=torch.long) for i in range(T)],
+                  "ts": self._loop_ts(B, dev).clone(),
                   # the graph bakes in raw pointers: it owns its workspace and holds the packed weights it captured
                   "ws": den.new_workspace(B, L, False, dev), "packed": packed,
                   "cproj": self._loop_cond_buffer(cond, packed, new=True)}
@@ -227,11 +254,17 @@ class GaussianDiffusion(nn.Module):
 
             def loop():
                 cur = 0
-                for i in reversed(range(T)):
-                    first = i == T - 1
-                    self._p_sample_bml(st["x"][cur], st["ts"][i], st["cond"], st["spk"], None, True,
+                vecs, st["vecs"] = None, []
+                for k in range(T):
+                    nxt = self._loop_step_vectors(st["ts"], k, st["spk"], packed, vecs)   # inside the graph: spk changes
+                    if nxt is not vecs:
+                        st["vecs"].append(nxt)         # the graph's kernels read these buffers on every replay
+                    vecs = nxt
+                    first = k == 0
+                    self._p_sample_bml(st["x"][cur], st["ts"][k], st["cond"], st["spk"], None, True,
                                        out=st["x"][cur ^ 1], packed=packed, ws=st["ws"],
-                                       cproj=None if first else st["cproj"], cproj_out=st["cproj"] if first else None)
+                                       cproj=None if first else st["cproj"], cproj_out=st["cproj"] if first else None,
+                                       step_vectors=None if vecs is None else (vecs[0], k - vecs[1], vecs[2]))
                     cur ^= 1
                 return cur
 

@@ -77,6 +77,14 @@ def test_p_sample_reading_the_projection_is_bitwise_the_same(mg, manifest, tmp_p
         c = gd._p_sample_bml(xd, td, cd, sd, nd, cproj_out=left)
         assert torch.equal(a, c) and torch.equal(left, cproj), "B=%d L=%d" % (B, L)
         assert torch.equal(a, gd._p_sample_bml(xd, td, cd, sd, nd, cproj=left))
+        # ... and the step-dependent vectors computed for three steps at once (this step in the middle)
+        ts = torch.stack([(td + 1) % 4, td, (td + 2) % 4])
+        vecs = den.step_vectors(ts, sd)
+        e = gd._p_sample_bml(xd, td, cd, sd, nd, cproj=left, step_vectors=(vecs, 1, 3))
+        assert torch.equal(a, e), "B=%d L=%d step vectors" % (B, L)
+        if B > 1:     # another step's slice gives another result: the slice is really read
+            other = gd._p_sample_bml(xd, td, cd, sd, nd, step_vectors=(vecs, 0, 3))
+            assert not torch.equal(a, other)
         if L <= 333:
             ref = R.p_sample(W, buf, x[:, None], t, cond, spk, nz[:, None], clip=True)
             assert_close(b.cpu()[:, None], ref, TOL, "p_sample with projection B=%d L=%d" % (B, L))
@@ -105,6 +113,31 @@ def test_sampling_loop_same_with_and_without_hoisting(mg, manifest, tmp_path, mo
         assert torch.equal(a, b)
 
 
+def test_long_loop_takes_its_step_vectors_in_chunks(mg, manifest, tmp_path, monkeypatch):
+    """T = 100 steps at B = 64: 1024 // 64 = 16 steps per chunk; the trace equals the loop that computes every step's
+    vectors by itself."""
+    e = golden("elementwise")
+    stats = write_stats(tmp_path, e["spec_min"], e["spec_max"])
+    gd = mg.GaussianDiffusion(*hot_path_configs("naive", 100, multi_speaker=True, stats_dir=stats))
+    load_seeded(gd.denoise_fn, manifest, "denoiser_ms1", 22)
+    gd = gd.cuda().eval()
+    B, L = 64, 40
+    gen = torch.Generator().manual_seed(37)
+    gd.cond = torch.randn(B, 256, L, generator=gen).cuda()
+    gd.spk_emb = torch.randn(B, 256, generator=gen).cuda()
+    start = torch.randn(B, 1, 80, L, generator=gen).cuda()
+    zeros = torch.zeros(B, 1, 80, L, device="cuda")
+    gd.noise_fn = lambda shape: zeros            # the posterior means: deterministic
+    calls = []
+    orig = gd.denoise_fn.step_vectors
+    monkeypatch.setattr(gd.denoise_fn, "step_vectors", lambda ts, spk, packed=None: calls.append(ts.shape[0]) or orig(ts, spk, packed))
+    a = gd.sampling(noise=start.clone(), keep_trace=False)[-1]
+    assert calls == [16] * 6 + [4]
+    monkeypatch.setenv("MG_COND_PREPROJECT", "0")
+    b = gd.sampling(noise=start.clone(), keep_trace=False)[-1]
+    assert len(calls) == 7 and torch.isfinite(a).all() and torch.equal(a, b)
+
+
 def test_launch_per_layer_path_fills_the_projections_too(mg, manifest, tmp_path, monkeypatch):
     """MG_DENOISER_PERSIST=0 (and every shape the single-launch kernels do not take): the step projects per layer as
     before and the buffer a later step may read is filled by the GEMM."""
@@ -119,7 +152,8 @@ def test_launch_per_layer_path_fills_the_projections_too(mg, manifest, tmp_path,
     left = torch.full((B, 5120, L), float("nan"), device="cuda")
     b = gd._p_sample_bml(x, t, cond, None, nz, cproj_out=left)
     assert torch.equal(left, den.cond_projection(cond))
-    c = gd._p_sample_bml(x, t, cond, None, nz, cproj=left)          # ignored by the per-layer kernels
+    vecs = den.step_vectors(torch.stack([t, t]), None)
+    c = gd._p_sample_bml(x, t, cond, None, nz, cproj=left, step_vectors=(vecs, 1, 2))   # ignored by the per-layer kernels
     assert torch.equal(b, c)
     assert_close(b.cpu(), a.cpu(), TOL, "per-layer path")
 
