@@ -31,7 +31,7 @@ B_PER_GPU = 16
 L_FRAMES = 1000
 MEL = 80
 FLOP_PER_FRAME = 23_805_952            # Denoiser.forward per frame
-COND_PROJ_FLOP_PER_FRAME = 20 * 2 * 256 * 256   # of which: the 20 conditioner projections (model/blocks.py:266)
+COND_PROJ_FLOP_PER_FRAME = 20 * 2 * 256 * 256   # of which: the 20 conditioner projections (model/blocks.py:1160)
 K3_FLOP_PER_FRAME = 2 * 512 * 768      # generic path's dominant kernel: Conv1d(256->512, k=3) of one layer
 # fused path's dominant kernel = one whole residual layer (model/blocks.py:1157-1176):
 # k=3 conv 256->512 + conditioner 1x1 256->256 + output 1x1 256->512 (algorithmic; halo MFMAs not counted)

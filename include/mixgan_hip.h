@@ -243,7 +243,7 @@ int mg_denoiser_fwd(const mg_denoiser_dims *d, const float *packed, const float 
 typedef struct mg_sampling_loop {
     /* cproj / cproj_out (fp32 MG_FWD_P16 packs only, at most one of them): the conditioner projections of all layers,
      * [B, n_layers * channels, L].  The steps of a loop call the denoiser with the SAME cond, and
-     * conditioner_projection(cond) (model/blocks.py:266) depends on neither x_t nor t: the first step passes cproj_out
+     * conditioner_projection(cond) (model/blocks.py:1160) depends on neither x_t nor t: the first step passes cproj_out
      * and leaves what it computed there, the steps behind it pass that buffer as cproj and skip the projections -- 11 %
      * of a step's multiply-adds.  (mg_denoiser_cond_project fills the same buffer without a step.)  The kernel forms
      * fl(fl(W_c cond + b_c) + fl(x + step)) either way. */
@@ -271,7 +271,7 @@ int mg_denoiser_psample(const mg_denoiser_dims *d, const float *packed, const fl
 size_t mg_denoiser_step_vectors_floats(const mg_denoiser_dims *d, int n, int B);
 int mg_denoiser_step_vectors(const mg_denoiser_dims *d, const float *packed, const int64_t *t, const float *spk,
                              float *vectors, size_t vectors_floats, int n, int B, void *stream);
-/* cproj[b, l * channels + c, :] = conditioner_projection_l(cond[b])[c, :] (model/blocks.py:251,266: Conv1d(H, C, 1) with
+/* cproj[b, l * channels + c, :] = conditioner_projection_l(cond[b])[c, :] (model/blocks.py:1150,1160: Conv1d(H, C, 1) with
  * bias) for every residual layer l, as one [n_layers * channels, H] x [H, B * L] product.  `packed` must have been built
  * with MG_DEN_P16 (channels == cond_channels == 256). */
 int mg_denoiser_cond_project(const mg_denoiser_dims *d, const float *packed, const float *cond, float *cproj, int B,

@@ -253,7 +253,7 @@ class Denoiser(nn.Module):
                 and packed is self._packed)
 
     def cond_projection(self, cond, out=None, packed=None):
-        """conditioner_projection(cond) of every residual layer (model/blocks.py:251,266) as one product:
+        """conditioner_projection(cond) of every residual layer (model/blocks.py:1150,1160) as one product:
         cond [B,H,L] -> [B, n_layers * C, L].  It depends on neither x_t nor t, so a T-step sampling loop
         (model/diffusion.py:133-147) computes it once and hands it to each p_sample(cproj=...)."""
         packed = self.packed_weights() if packed is None else packed

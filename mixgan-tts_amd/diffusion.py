@@ -130,7 +130,7 @@ class GaussianDiffusion(nn.Module):
                                         cproj_out, step_vectors)
 
     # The T steps of a sampling loop (model/diffusion.py:133-147) see the same conditioner, and each residual layer's
-    # conditioner_projection(cond) (model/blocks.py:266) depends on neither x_t nor t: the first step of a loop leaves
+    # conditioner_projection(cond) (model/blocks.py:1160) depends on neither x_t nor t: the first step of a loop leaves
     # its projections in a buffer and the steps behind it read them instead of projecting again (bit-identical results;
     # MG_COND_PREPROJECT=0 or cond_preproject = False: every step projects).
     cond_preproject = True

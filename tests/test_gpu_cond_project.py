@@ -1,5 +1,5 @@
 """The x_t-independent conditioner projections of a sampling loop, hoisted out of its steps (mg_denoiser_cond_project +
-mg_denoiser_psample's cproj): conditioner_projection(cond) of model/blocks.py:251,266 for all residual layers at once,
+mg_denoiser_psample's cproj): conditioner_projection(cond) of model/blocks.py:1150,1160 for all residual layers at once,
 and p_sample reading it instead of projecting inside the kernel -- the same x_{t-1} bit for bit, on every tile width."""
 import pytest
 import torch
