@@ -134,6 +134,7 @@ class GaussianDiffusion(nn.Module):
     # its projections in a buffer and the steps behind it read them instead of projecting again (bit-identical results;
     # MG_COND_PREPROJECT=0 or cond_preproject = False: every step projects).
     cond_preproject = True
+    cond_preproject_max_bytes = 32 << 30      # 20 KB per frame: B=16, L=1000 is 328 MB; beyond this the steps project
 
     def _preprojects(self, packed):
         return (self.cond_preproject and self.num_timesteps >= 2 and os.environ.get("MG_COND_PREPROJECT", "1") != "0"
@@ -147,6 +148,8 @@ class GaussianDiffusion(nn.Module):
             return None
         B, _, L = cond.shape
         shape = (B, den._dims.n_layers * den._dims.channels, L)
+        if 4 * shape[0] * shape[1] * shape[2] > self.cond_preproject_max_bytes:
+            return None
         if new:
             return torch.empty(shape, device=cond.device, dtype=torch.float32)
         key = (B, L, cond.device, torch.cuda.current_stream(cond.device).cuda_stream)

@@ -56,7 +56,7 @@ def main():
         with torch.no_grad():
             gd(None, cond, None, pad, coarse)
         iters = 3 if T >= 100 else 20
-        te = timeit(lambda: gd.sampling(keep_trace=False), 1, iters)
+        te = timeit(lambda: gd.sampling(keep_trace=False), 1 if T >= 100 else 3, iters)
         tg = timeit(lambda: gd.sampling(keep_trace=False, use_graph=True), 2, iters)
         out.append({"config": name, "sampling_eager_ms": round(te * 1e3, 3), "sampling_hipgraph_ms": round(tg * 1e3, 3),
                     "denoiser_steps_per_s_eager": round(T / te, 1), "denoiser_steps_per_s_graph": round(T / tg, 1),
