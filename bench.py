@@ -225,9 +225,12 @@ def main():
         def roof(precision, k_ms, n_ev, dt, hoisted=False):
             generic = os.environ.get("MG_DENOISER_GENERIC") is not None and precision == "fp32"
             single = single_launch(precision)
-            # with the conditioner projections hoisted, T-1 of T launches execute 20 x 2 x 256 x 256 fewer flops per frame
+            # `achieved` is the contract's figure: the ALGORITHMIC flops of the step a launch delivers (SURVEY.md section
+            # 8d: the reference's Denoiser.forward, 23,805,952 per frame) / the launch's duration.  With the conditioner
+            # projections hoisted, T-1 of T launches EXECUTE 20 x 2 x 256 x 256 fewer flops per frame than that:
+            # `executed` prices the matrix pipes' actual load (what SQ_VALU_MFMA_BUSY sees).
             in_launch = FLOP_PER_FRAME - (COND_PROJ_FLOP_PER_FRAME * (T - 1) / T if hoisted else 0)
-            k_flop = (in_launch if single
+            k_flop = (FLOP_PER_FRAME if single
                       else K3_FLOP_PER_FRAME if generic else LAYER_FLOP_PER_FRAME) * B * L
             achieved = k_flop / (k_ms * 1e-3) / 1e12
             whole = FLOP_PER_FRAME * B * L * args.steps / dt / 1e12
@@ -251,13 +254,14 @@ def main():
                  "traffic": None, "kernel_ms": round(k_ms, 4),
                  "launches_timed": n_ev, "whole_step_tflops": round(whole, 2),
                  "whole_step_frac": round(whole / peak, 4)}
-            if hoisted:
-                r["flop_per_frame_in_launch"] = in_launch
-                r["note"] = ("achieved counts only what the launches execute: the 20 conditioner projections "
-                             "(%d of the step's %d flop/frame) run in the first launch of every %d-step loop, which "
-                             "leaves them for the other %d (mean over the timed launches of both kinds); whole_step_* "
-                             "prices the full reference step in every launch against the wall clock"
-                             % (COND_PROJ_FLOP_PER_FRAME, FLOP_PER_FRAME, T, T - 1))
+            if hoisted and single:
+                ex = in_launch * B * L / (k_ms * 1e-3) / 1e12
+                r["executed"] = {"flop_per_frame": in_launch, "tflops": round(ex, 2), "frac": round(ex / peak, 4)}
+                r["note"] = ("achieved = the reference step's %d flop/frame per launch (SURVEY 8d) / mean launch duration; "
+                             "the 20 conditioner projections (%d flop/frame, x_t-independent) are computed by the first "
+                             "launch of every %d-step loop and read by the other %d, so the launches execute less than "
+                             "they deliver: `executed` is the matrix pipes' own load (mean over both kinds of launches)"
+                             % (FLOP_PER_FRAME, COND_PROJ_FLOP_PER_FRAME, T, T - 1))
             if single and precision == "fp32" and (B, L) == (B_PER_GPU, L_FRAMES):
                 r["traffic"], r["traffic_source"] = tracked_traffic(hoisted)
             r.update(extra)
