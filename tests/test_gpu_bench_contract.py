@@ -38,11 +38,25 @@ def test_default_workload_line():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.3 < r["frac"] < 1.0
     assert r["launches_timed"] == 4 and r["traffic"] > 8e7 and "profiles/" in r["traffic_source"]
+    # the loop-invariant work is hoisted by default: the line says so and prices the executed flops beside the algorithmic
+    assert "cond_projection" in d["config"] and 0.3 < r["executed"]["frac"] < r["frac"]
+    assert r["executed"]["flop_per_frame"] == 23805952 - 0.75 * 2621440
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     par = c["parity"]
     assert par["x0_pred"]["max_abs_over_max_ref"] < par["tolerance"] == 1e-3
     assert par["final_mel"]["max_abs_over_max_ref"] < 1e-3
+
+
+def test_both_legs_and_the_per_step_headline():
+    d = _run(["--steps", "8", "--warmup", "4", "--no-cpu-baseline"])          # with the alt legs
+    p = d["projection_in_every_step"]
+    assert p["unit"] == "steps/s" and 0.5 * d["value"] < p["value"] < 1.02 * d["value"]
+    assert "executed" not in p["roofline"] and p["roofline"]["launches_timed"] == 8
+    assert d["alt"]["dtype"].startswith("bf16x3")
+    q = _run(["--steps", "8", "--warmup", "4", "--no-cpu-baseline", "--no-alt", "--project-per-step"])
+    assert "cond_projection" not in q["config"] and "executed" not in q["roofline"]
+    assert "projection_in_every_step" not in q
 
 
 def test_train_workload_line():
