@@ -859,10 +859,15 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
             const char *fe = std::getenv("MG_PERSIST_FLAGS");
             a.flags = fe ? std::atoi(fe) : DP_F_ROLES;
         }
-        const bool vec4 = (L % 4 == 0) && (((uintptr_t)cond & 15) == 0);
+        // (16-byte rows for the float4 staging of cond and for the LDS-direct fetches of its projections)
+        const bool vec4 = (L % 4 == 0) && (((uintptr_t)cond & 15) == 0) && (((uintptr_t)a.cproj & 15) == 0);
         dim3 grid((unsigned)(tiles_per_b * B));
         prof_mark(st, 0);
 #define MG_DP_LAUNCH(NT, V, T, S) hipLaunchKernelGGL((denoiser_persist_kernel<NT, V, T, S>), grid, dim3(NT * 8), 0, st, a)
+// a step that reads its conditioner projections (a.cproj): the instantiation without GEMM 1
+#define MG_DP_LAUNCH_R(NT, V, T, NWV) \
+    hipLaunchKernelGGL((denoiser_persist_kernel<NT, V, T, false, NWV, true>), grid, dim3(NWV * 64), 0, st, a)
+        const bool readp = a.cproj != nullptr && !save;
         if (nt == 16 && team == 4) {
             const dim3 tgrid((unsigned)(tiles_per_b * B * 4));
             if (vec4) hipLaunchKernelGGL((denoiser_team16_kernel<true, 4>), tgrid, dim3(256), 0, st, a);
@@ -878,6 +883,10 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
             if (save) {
                 if (vec4) MG_DP_LAUNCH(64, true, false, true);
                 else MG_DP_LAUNCH(64, false, false, true);
+            } else if (readp) {
+                if (g_persist_dbg && vec4) MG_DP_LAUNCH_R(64, true, true, 8);
+                else if (vec4) MG_DP_LAUNCH_R(64, true, false, 8);
+                else MG_DP_LAUNCH_R(64, false, false, 8);
             } else if (g_persist_dbg && vec4) MG_DP_LAUNCH(64, true, true, false);
             else if (vec4) MG_DP_LAUNCH(64, true, false, false);
             else MG_DP_LAUNCH(64, false, false, false);
@@ -886,6 +895,9 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
             if (save) {
                 if (vec4) MG_DP_LAUNCH8(true, true);
                 else MG_DP_LAUNCH8(false, true);
+            } else if (readp) {
+                if (vec4) MG_DP_LAUNCH_R(32, true, false, 8);
+                else MG_DP_LAUNCH_R(32, false, false, 8);
             } else if (vec4) MG_DP_LAUNCH8(true, false);
             else MG_DP_LAUNCH8(false, false);
 #undef MG_DP_LAUNCH8
@@ -893,10 +905,14 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
             if (save) {
                 if (vec4) MG_DP_LAUNCH(32, true, false, true);
                 else MG_DP_LAUNCH(32, false, false, true);
+            } else if (readp) {
+                if (vec4) MG_DP_LAUNCH_R(32, true, false, 4);
+                else MG_DP_LAUNCH_R(32, false, false, 4);
             } else if (g_persist_dbg && vec4) MG_DP_LAUNCH(32, true, true, false);
             else if (vec4) MG_DP_LAUNCH(32, true, false, false);
             else MG_DP_LAUNCH(32, false, false, false);
         }
+#undef MG_DP_LAUNCH_R
 #undef MG_DP_LAUNCH
         prof_mark(st, 1);
         MG_LAUNCH_CHECK();

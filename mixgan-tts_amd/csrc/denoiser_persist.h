@@ -233,9 +233,37 @@ __device__ __forceinline__ bool dp_failed(unsigned *sync)
 }
 #define DP_STAMP(k) do { if (TIMING && tid == 0) a.dbg[((size_t)tile * (a.NL + 2) + stamp_row) * 12 + (k)] = clock64(); } while (0)
 
-template <int NT, bool VEC4, bool TIMING = false, bool SAVE = false, int NWV = NT / 8>
+// A reading step's conditioner projections (PersistArgs.cproj) come through LDS: wave w fetches the NT columns of its own
+// RW rows of layer l's [256, L] block straight into the (otherwise unused) conditioner tile region with LDS-direct loads
+// -- no registers, issued a phase ahead -- 64 lanes x 16 bytes = 1 KB = 1024 / (4 NT) whole rows per instruction, plain
+// row-major with stride NT.  Only the issuing wave reads what it fetched: its own vmcnt(0) is the only synchronisation.
+// L % 4 == 0 and a 16-byte aligned base (the launcher checks); a lane past the utterance's end re-reads the row's last
+// vector (those columns are never used).  Written as inline assembly on purpose: the compiler orders every later LDS
+// access behind an LDS-direct load it knows of (s_waitcnt vmcnt(0) in front of the gate's first ds_write), which would
+// put the whole memory latency back on the critical path.
+template <int NT, int RW>
+__device__ __forceinline__ void dp_cproj_fetch(const float *cp, float *cl, int w, int lane, int l0, int L)
+{
+    constexpr int LPR = NT / 4;     // lanes per row
+    constexpr int RPI = 64 / LPR;   // rows per instruction
+    const int rsub = lane / LPR, c4 = lane - rsub * LPR;
+    const float *g = cp + (size_t)(RW * w + rsub) * L + min(l0 + 4 * c4, L - 4);
+    float *dst = cl + (size_t)RW * w * NT;
+    const unsigned at = (unsigned)(size_t)(__attribute__((address_space(3))) void *)dst;   // LDS byte address, wave-uniform
+#pragma unroll
+    for (int it = 0; it < RW / RPI; ++it) {
+        const float *gi = g + (size_t)it * RPI * L;
+        const unsigned m = __builtin_amdgcn_readfirstlane(at + (unsigned)(it * RPI * NT * 4));
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m), "v"(gi) : "memory");   // (m0 is reserved: the compiler loads it in front of each of its own uses)
+    }
+}
+
+// READP: a step that READS its conditioner projections (a.cproj != NULL) -- its own instantiation, without GEMM 1 and the
+// conditioner tile, so that neither kind of step carries the other's registers.
+template <int NT, bool VEC4, bool TIMING = false, bool SAVE = false, int NWV = NT / 8, bool READP = false>
 __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistArgs a)
 {
+    static_assert(!(READP && SAVE), "the saving forward computes its projections");
     static_assert((NT == 32 && (NWV == 4 || NWV == 8)) || (NT == 64 && NWV == 8),
                   "tile widths: 32 frames (4 waves, two workgroups per CU; or 8 waves, one per CU) or 64 (8 waves, one)");
     constexpr int NTHR = NWV * 64, NW = NWV;        // threads, waves
@@ -296,8 +324,9 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
     // ---------------------------------------------------------------- stage the cond tile (once) and the x_t tile
     {
         const float *cb = (second ? a.cond2 : a.cond) + (size_t)b * RB_C * L;
-        if (a.cproj) {
-            // the conditioner enters only through its precomputed projections: no tile to stage
+        if (READP) {
+            // the conditioner enters only through its precomputed projections: no tile to stage; layer 0's are fetched
+            if (VEC4) dp_cproj_fetch<NT, 32 * MB>(a.cproj + (size_t)b * a.NL * RB_C * L, lds, w, lane, l0, L);
         } else if (VEC4) {
 #pragma unroll
             for (int k = 0; k < 64 * NT / NTHR; ++k) {   // 256 rows x NT/4 float4 (frames l0 .. l0+NT-1)
@@ -399,7 +428,17 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
         // instead of one per layer and step).  Both ways evaluate fl(fl(sum_k + bc) + fl(x + vec)) with the sum over k
         // accumulated from zero in channel order -- bit-identical results.
         f32x16 acc1[MB][NNB];
-        if (a.cproj) {
+        if (READP && VEC4) {
+            // fetched into LDS a phase ago by this wave itself (dp_cproj_fetch): wait for its own loads, read, and the
+            // region is free for the next layer's
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NNB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc1[i][j][r] = lds[row_of(i, r) * NT + 32 * j + c32];
+        } else if (READP) {
             const float *cp = a.cproj + ((size_t)b * a.NL + l) * RB_C * L;
 #pragma unroll
             for (int i = 0; i < MB; ++i)
@@ -474,6 +513,12 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
                                    [&](int r) { return fvalid[j] ? acc1[i][j][r] : 0.f; });
                 if (SAVE && do_save) save_block(a.h_save + (size_t)l * a.act_stride, rbase + 32 * i, j, [&](int r) { return acc1[i][j][r]; });
             }
+        // The next layer's conditioner projections: on their way for the rest of this layer.  Issued HERE because vector
+        // loads return in order -- whatever load is waited for next also waits for these: behind the h stores (which
+        // need everything loaded so far, so no earlier wait can sink below the fetch) the next one is GEMM 2's first
+        // weight fragment, a barrier, the halo publish and an L2 round trip away.
+        if (READP && VEC4 && l + 1 < a.NL)
+            dp_cproj_fetch<NT, 32 * MB>(a.cproj + ((size_t)b * a.NL + l + 1) * RB_C * L, lds, w, lane, l0, L);
         __syncthreads();   // interior columns of hT complete
         DP_STAMP(3);
 

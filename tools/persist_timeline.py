@@ -30,13 +30,24 @@ cond = torch.randn(B, 256, L, device="cuda")
 t = torch.full((B,), 3, device="cuda", dtype=torch.long)
 NT = int(os.environ.get('MG_PERSIST_NT', 64 if B * ((L + 63) // 64) > 128 else 32))
 tiles = B * ((L + NT - 1) // NT)
+# CPROJ=1: a step that READS the loop's conditioner projections instead of computing them
+cproj = den.cond_projection(cond) if os.environ.get("CPROJ") == "1" else None
+
+
+def launch():
+    if cproj is None:
+        den.run(x, t, cond, None)
+    else:
+        gd._p_sample_bml(x, t, cond, None, None, cproj=cproj)
+
+
 for _ in range(3):
-    den.run(x, t, cond, None)
+    launch()
 stamps = torch.zeros(tiles * (NL + 2) * 12, dtype=torch.int64, device="cuda")
 lib = mg.lib()
 lib.mg_debug_persist_stamps.argtypes = [ctypes.c_void_p]
 lib.mg_debug_persist_stamps(ctypes.c_void_p(stamps.data_ptr()))
-den.run(x, t, cond, None)
+launch()
 torch.cuda.synchronize()
 lib.mg_debug_persist_stamps(ctypes.c_void_p(0))
 s = stamps.cpu().numpy().reshape(tiles, NL + 2, 12).astype(np.float64)
