@@ -245,8 +245,9 @@ typedef struct mg_sampling_loop {
      * [B, n_layers * channels, L].  The steps of a loop call the denoiser with the SAME cond, and
      * conditioner_projection(cond) (model/blocks.py:1160) depends on neither x_t nor t: the first step passes cproj_out
      * and leaves what it computed there, the steps behind it pass that buffer as cproj and skip the projections -- 11 %
-     * of a step's multiply-adds.  (mg_denoiser_cond_project fills the same buffer without a step.)  The kernel forms
-     * fl(fl(W_c cond + b_c) + fl(x + step)) either way. */
+     * of a step's multiply-adds.  The kernels form fl(P + fl(x + step)) either way, P = b_c with the products W_c cond
+     * added onto it in channel order -- a function of cond alone.  (mg_denoiser_cond_project fills the same buffer without
+     * a step; it adds b_c behind the sum, so its P may differ from a kernel's in the last bit.) */
     const float *cproj;
     float *cproj_out;
     /* step_vectors: mg_denoiser_step_vectors' output for all step_count steps of the loop (a loop knows its t values

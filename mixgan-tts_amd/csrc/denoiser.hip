@@ -864,10 +864,15 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
         dim3 grid((unsigned)(tiles_per_b * B));
         prof_mark(st, 0);
 #define MG_DP_LAUNCH(NT, V, T, S) hipLaunchKernelGGL((denoiser_persist_kernel<NT, V, T, S>), grid, dim3(NT * 8), 0, st, a)
-// a step that reads its conditioner projections (a.cproj): the instantiation without GEMM 1
-#define MG_DP_LAUNCH_R(NT, V, T, NWV) \
-    hipLaunchKernelGGL((denoiser_persist_kernel<NT, V, T, false, NWV, true>), grid, dim3(NWV * 64), 0, st, a)
-        const bool readp = a.cproj != nullptr && !save;
+// a step that stores (CPM 1: a.cproj_out) or reads (CPM 2: a.cproj) its conditioner projections: own instantiations
+#define MG_DP_LAUNCH_C(NT, V, T, NWV, CPM) \
+    hipLaunchKernelGGL((denoiser_persist_kernel<NT, V, T, false, NWV, CPM>), grid, dim3(NWV * 64), 0, st, a)
+#define MG_DP_LAUNCH_R(NT, V, T, NWV)                  \
+    do {                                               \
+        if (a.cproj) MG_DP_LAUNCH_C(NT, V, T, NWV, 2); \
+        else MG_DP_LAUNCH_C(NT, V, T, NWV, 1);         \
+    } while (0)
+        const bool readp = (a.cproj != nullptr || a.cproj_out != nullptr) && !save;   // (the launch has a loop's buffer)
         if (nt == 16 && team == 4) {
             const dim3 tgrid((unsigned)(tiles_per_b * B * 4));
             if (vec4) hipLaunchKernelGGL((denoiser_team16_kernel<true, 4>), tgrid, dim3(256), 0, st, a);
@@ -913,6 +918,7 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
             else MG_DP_LAUNCH(32, false, false, false);
         }
 #undef MG_DP_LAUNCH_R
+#undef MG_DP_LAUNCH_C
 #undef MG_DP_LAUNCH
         prof_mark(st, 1);
         MG_LAUNCH_CHECK();

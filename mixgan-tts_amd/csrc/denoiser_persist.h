@@ -247,23 +247,30 @@ __device__ __forceinline__ void dp_cproj_fetch(const float *cp, float *cl, int w
     constexpr int LPR = NT / 4;     // lanes per row
     constexpr int RPI = 64 / LPR;   // rows per instruction
     const int rsub = lane / LPR, c4 = lane - rsub * LPR;
-    const float *g = cp + (size_t)(RW * w + rsub) * L + min(l0 + 4 * c4, L - 4);
+    // one 32-bit byte offset per lane, recomputed at every call (the opaque asm: nothing address-like stays live across the
+    // layer loop), on top of a uniform base per instruction
+    unsigned off = (unsigned)(((RW * w + rsub) * L + min(l0 + 4 * c4, L - 4)) * 4);
+    asm volatile("" : "+v"(off));
     float *dst = cl + (size_t)RW * w * NT;
     const unsigned at = (unsigned)(size_t)(__attribute__((address_space(3))) void *)dst;   // LDS byte address, wave-uniform
 #pragma unroll
     for (int it = 0; it < RW / RPI; ++it) {
-        const float *gi = g + (size_t)it * RPI * L;
+        const float *gi = cp + (size_t)it * RPI * L;   // uniform
         const unsigned m = __builtin_amdgcn_readfirstlane(at + (unsigned)(it * RPI * NT * 4));
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(m), "v"(gi) : "memory");   // (m0 is reserved: the compiler loads it in front of each of its own uses)
+        // (m0 is reserved: the compiler loads it in front of each of its own uses)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(m), "v"(off), "s"(gi) : "memory");
     }
 }
 
-// READP: a step that READS its conditioner projections (a.cproj != NULL) -- its own instantiation, without GEMM 1 and the
-// conditioner tile, so that neither kind of step carries the other's registers.
-template <int NT, bool VEC4, bool TIMING = false, bool SAVE = false, int NWV = NT / 8, bool READP = false>
+// CPM: what the launch does with the conditioner projections -- 0: computes them, 1: computes and stores them
+// (a.cproj_out), 2: reads them (a.cproj): its own instantiation without GEMM 1 and the conditioner tile.  Compile-time, so
+// that no kind of step carries another's registers (as run-time branches the stores cost the plain step 34 spilled
+// registers and 2 % of its time).
+template <int NT, bool VEC4, bool TIMING = false, bool SAVE = false, int NWV = NT / 8, int CPM = 0>
 __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistArgs a)
 {
-    static_assert(!(READP && SAVE), "the saving forward computes its projections");
+    static_assert(!(CPM && SAVE), "the saving forward computes its projections and keeps none");
+    constexpr bool READP = CPM == 2, WRITEP = CPM == 1;
     static_assert((NT == 32 && (NWV == 4 || NWV == 8)) || (NT == 64 && NWV == 8),
                   "tile widths: 32 frames (4 waves, two workgroups per CU; or 8 waves, one per CU) or 64 (8 waves, one)");
     constexpr int NTHR = NWV * 64, NW = NWV;        // threads, waves
@@ -425,8 +432,8 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
         // ------------------------------------------------------------ GEMM 1: h = (Wc cond + bc) + (x + (Wd s [+ Wp spk]))
         // The first bracket does not depend on x_t: inside a T-step sampling loop it is the same in every step, and the
         // caller may hand it over precomputed for all layers (a.cproj, mg_denoiser_cond_project: one GEMM per loop
-        // instead of one per layer and step).  Both ways evaluate fl(fl(sum_k + bc) + fl(x + vec)) with the sum over k
-        // accumulated from zero in channel order -- bit-identical results.
+        // instead of one per layer and step).  Both ways evaluate fl(P + fl(x + vec)), P = bc with the products added onto
+        // it in channel order (the accumulators START at bc: P is a function of cond alone) -- bit-identical results.
         f32x16 acc1[MB][NNB];
         if (READP && VEC4) {
             // fetched into LDS a phase ago by this wave itself (dp_cproj_fetch): wait for its own loads, read, and the
@@ -438,15 +445,16 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
                 for (int j = 0; j < NNB; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc1[i][j][r] = lds[row_of(i, r) * NT + 32 * j + c32];
-        } else if (READP) {
+        } else if (READP) {   // L % 4 != 0: straight from global memory (uniform base + lane offsets as for the stores below)
             const float *cp = a.cproj + ((size_t)b * a.NL + l) * RB_C * L;
 #pragma unroll
             for (int i = 0; i < MB; ++i)
 #pragma unroll
                 for (int j = 0; j < NNB; ++j) {
-                    const int fcj = min(l0 + 32 * j + c32, L - 1);
+                    unsigned lo = (unsigned)((rbase + 4 * hh) * L + min(l0 + 32 * j + c32, L - 1));
+                    asm volatile("" : "+v"(lo));
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc1[i][j][r] = cp[(size_t)row_of(i, r) * L + fcj];
+                    for (int r = 0; r < 16; ++r) acc1[i][j][r] = cp[lo + (unsigned)((32 * i + 8 * (r >> 2) + (r & 3)) * L)];
                 }
         } else {
 #pragma unroll
@@ -454,30 +462,27 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
 #pragma unroll
                 for (int j = 0; j < NNB; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) acc1[i][j][r] = lp[a.l_bc + row_of(i, r)];
             const f32x4 *wc = reinterpret_cast<const f32x4 *>(lp + a.l_wc);
             const f32x4 *ap[MB];
 #pragma unroll
             for (int i = 0; i < MB; ++i) ap[i] = wc + (size_t)(MB * w + i) * 32 * 64 + lane;
             dp_mfma_loop<MB, NNB, NC, DpIterK1>(acc1, ap, condT + c32 * 8 + hh * 4);
-#pragma unroll
-            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                for (int j = 0; j < NNB; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc1[i][j][r] += lp[a.l_bc + row_of(i, r)];
-            if (a.cproj_out) {   // the first step of a sampling loop leaves the projections for the steps behind it
+            if (WRITEP) {   // the first step of a sampling loop leaves the projections for the steps behind it
+                // uniform base + a 32-bit lane offset that is recomputed every layer (the opaque asm): kept live across
+                // the layer loop, 32 store addresses cost 34 spilled registers
                 float *co = a.cproj_out + ((size_t)b * a.NL + l) * RB_C * L;
+                unsigned lo = (unsigned)((rbase + 4 * hh) * L + l0 + c32);
+                asm volatile("" : "+v"(lo));
 #pragma unroll
                 for (int i = 0; i < MB; ++i)
 #pragma unroll
-                    for (int j = 0; j < NNB; ++j) {
-                        const int fcj = l0 + 32 * j + c32;
-                        if (fcj < L) {
+                    for (int j = 0; j < NNB; ++j)
+                        if (l0 + 32 * j + c32 < L) {
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) co[(size_t)row_of(i, r) * L + fcj] = acc1[i][j][r];
+                            for (int r = 0; r < 16; ++r)
+                                co[lo + (unsigned)((32 * i + 8 * (r >> 2) + (r & 3)) * L + 32 * j)] = acc1[i][j][r];
                         }
-                    }
             }
         }
 #pragma unroll

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void denoiser_persist16_kernel(PersistArgs 
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc1[i][r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc1[i][r] = lp[a.l_bc + row_of(i, r)];   // the accumulators start at bc
         if (a.cproj) {   // (Wc cond + bc) precomputed for the whole sampling loop: see denoiser_persist.h
             const float *cp = a.cproj + ((size_t)b * a.NL + l) * RB_C * L + min(f, L - 1);
 #pragma unroll
@@ -193,10 +193,6 @@ __global__ __launch_bounds__(256, 2) void denoiser_persist16_kernel(PersistArgs 
             const f32x4 *const ap[4] = {blk(pp + a.p_wc, 4 * w, 32), blk(pp + a.p_wc, 4 * w + 1, 32),
                                         blk(pp + a.p_wc, 4 * w + 2, 32), blk(pp + a.p_wc, 4 * w + 3, 32)};
             d16_mfma_loop<4, NC, D16IterK1>(acc1, ap, condT + c16 * 16 + g * 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc1[i][r] += lp[a.l_bc + row_of(i, r)];
             if (a.cproj_out && f < L) {
                 float *co = a.cproj_out + ((size_t)b * a.NL + l) * RB_C * L + f;
 #pragma unroll
@@ -208,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void denoiser_persist16_kernel(PersistArgs 
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc1[i][r] += X[i][r] + hv[row_of(i, r)];   // fl(fl(sum + bc) + fl(x + vec)) either way
+            for (int r = 0; r < 4; ++r) acc1[i][r] += X[i][r] + hv[row_of(i, r)];   // fl(P + fl(x + vec)) either way
         // GEMM 2's accumulators start at the conv bias.  Pass p covers channels 64w + 32p .. +31:
         // acc2[p][0..1] = gate rows (two 16-row blocks), acc2[p][2..3] = filter rows
         f32x4 acc2[2][4];

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(1024 / TEAM, 2) void denoiser_team16_kernel(Persist
         // ------------------------------------------------------------ GEMM 1: h = Wc cond + bc + x + (Wd s [+ Wp spk])
         f32x4 acc1[1];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc1[0][r] = 0.f;
+        for (int r = 0; r < 4; ++r) acc1[0][r] = lp[a.l_bc + row_of(r)];   // the accumulators start at bc
         if (a.cproj) {   // (Wc cond + bc) precomputed for the whole sampling loop: see denoiser_persist.h
             const float *cp = a.cproj + ((size_t)b * a.NL + l) * RB_C * L + min(f, L - 1);
 #pragma unroll
@@ -262,8 +262,6 @@ __global__ __launch_bounds__(1024 / TEAM, 2) void denoiser_team16_kernel(Persist
         } else {
             const f32x4 *const ap[1] = {blk(pp + a.p_wc, cb, 32)};
             d16_mfma_loop_deep<1, NC, D16IterK1>(acc1, ap, condT + c16 * 16 + g * 4, ringA);   // preloaded a phase ago
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc1[0][r] += lp[a.l_bc + row_of(r)];
             if (a.cproj_out && f < L) {
                 float *co = a.cproj_out + ((size_t)b * a.NL + l) * RB_C * L + f;
 #pragma unroll
@@ -271,7 +269,7 @@ __global__ __launch_bounds__(1024 / TEAM, 2) void denoiser_team16_kernel(Persist
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc1[0][r] += XS[0][r] + hv[row_of(r)];   // fl(fl(sum + bc) + fl(x + vec)) either way
+        for (int r = 0; r < 4; ++r) acc1[0][r] += XS[0][r] + hv[row_of(r)];   // fl(P + fl(x + vec)) either way
         // GEMM 2's first weights: requested now, needed behind the h exchange
         const int c32 = cb >> 1, half = cb & 1;   // GATE16 packs: per 32 channels, blocks {gate lo, gate hi, filter lo, filter hi}
         const f32x4 *const ap2[2] = {blk(pp + a.p_w3, 4 * c32 + half, 96), blk(pp + a.p_w3, 4 * c32 + 2 + half, 96)};

@@ -68,15 +68,18 @@ def test_p_sample_reading_the_projection_is_bitwise_the_same(mg, manifest, tmp_p
         t = torch.tensor([3, 0, 2, 1][:B])
         xd, cd, nd, td = x.cuda(), cond.cuda(), nz.cuda(), t.cuda()
         sd = None if spk is None else spk.cuda()
-        cproj = den.cond_projection(cd)
         a = gd._p_sample_bml(xd, td, cd, sd, nd)
-        b = gd._p_sample_bml(xd, td, cd, sd, nd, cproj=cproj)
-        assert torch.equal(a, b), "B=%d L=%d: %g" % (B, L, (a - b).abs().max().item())
-        # ... and a step that leaves its own projections behind: the same x_{t-1}, the same projections as the GEMM
-        left = torch.full_like(cproj, float("nan"))
+        # a step that leaves its projections behind: the same x_{t-1} bit for bit, and so is a step that reads them
+        left = torch.full((B, 20 * 256, L), float("nan"), device="cuda")
         c = gd._p_sample_bml(xd, td, cd, sd, nd, cproj_out=left)
-        assert torch.equal(a, c) and torch.equal(left, cproj), "B=%d L=%d" % (B, L)
-        assert torch.equal(a, gd._p_sample_bml(xd, td, cd, sd, nd, cproj=left))
+        assert torch.equal(a, c), "B=%d L=%d: %g" % (B, L, (a - c).abs().max().item())
+        b = gd._p_sample_bml(xd, td, cd, sd, nd, cproj=left)
+        assert torch.equal(a, b), "B=%d L=%d: %g" % (B, L, (a - b).abs().max().item())
+        # the stand-alone GEMM adds the bias behind the sum, the kernels start their accumulators at it: the same
+        # projections to the last bit or two, and a step reading them stays within the parity tolerance
+        cproj = den.cond_projection(cd)
+        assert_close(left.cpu(), cproj.cpu(), 2e-6, "in-kernel projections vs the GEMM B=%d L=%d" % (B, L))
+        assert_close(gd._p_sample_bml(xd, td, cd, sd, nd, cproj=cproj).cpu(), a.cpu(), TOL, "reading the GEMM's")
         # ... and the step-dependent vectors computed for three steps at once (this step in the middle)
         ts = torch.stack([(td + 1) % 4, td, (td + 2) % 4])
         vecs = den.step_vectors(ts, sd)
@@ -108,7 +111,7 @@ def test_sampling_loop_same_with_and_without_hoisting(mg, manifest, tmp_path, mo
         outs.append(trace)
     gd.noise_fn = None
     assert gd._cproj_buf is not None and gd._cproj_buf[1].shape == (B, 20 * 256, L)
-    assert torch.equal(gd._cproj_buf[1], gd.denoise_fn.cond_projection(gd.cond))
+    assert_close(gd._cproj_buf[1].cpu(), gd.denoise_fn.cond_projection(gd.cond).cpu(), 2e-6, "the loop's projections")
     for a, b in zip(*outs):
         assert torch.equal(a, b)
 
@@ -179,7 +182,8 @@ def test_graphed_sampling_loop_projects_inside_the_graph(mg, manifest, tmp_path)
     a2 = gd.sampling(noise=start.clone(), keep_trace=False, use_graph=True)[-1]
     p2 = gd._graph["cproj"]
     assert torch.isfinite(a1).all() and torch.isfinite(a2).all()
-    assert torch.equal(p1, gd.denoise_fn.cond_projection(c1)) and torch.equal(p2, gd.denoise_fn.cond_projection(c2))
+    assert_close(p1.cpu(), gd.denoise_fn.cond_projection(c1).cpu(), 2e-6, "first replay's projections")
+    assert_close(p2.cpu(), gd.denoise_fn.cond_projection(c2).cpu(), 2e-6, "second replay's projections")
     assert p2.data_ptr() != gd._loop_cond_buffer(c2, gd.denoise_fn.packed_weights()).data_ptr()   # the graph owns its buffer
     assert not torch.equal(a1, a2)
 
