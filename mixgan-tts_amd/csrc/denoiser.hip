@@ -847,6 +847,11 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
         a.n_steps = post ? post->n_steps : 1;
         a.rsNL = 1.0f / sqrtf((float)NL);
         a.dbg = g_persist_dbg;
+        {
+            const char *we = g_persist_dbg ? std::getenv("MG_PERSIST_DBG_WAVE") : nullptr;
+            a.dbg_wave = we ? std::atoi(we) & 7 : 0;
+            if (a.dbg_wave >= (nt == 32 && !wide32 ? 4 : 8)) a.dbg_wave = 0;
+        }
         a.x0_save = save ? ws + w.x0 : nullptr;
         a.y_save = save ? ws + w.y : nullptr;
         a.skip_save = save ? ws + w.skip : nullptr;
@@ -1131,6 +1136,7 @@ extern "C" int mg_denoiser_fwd_pair(const mg_denoiser_dims *d, const float *pack
     a.n_steps = 1;
     a.rsNL = 1.0f / sqrtf((float)NL);
     a.dbg = nullptr;
+    a.dbg_wave = 0;
     a.x0_save = wsB + wB.x0;
     a.y_save = wsB + wB.y;
     a.skip_save = wsB + wB.skip;

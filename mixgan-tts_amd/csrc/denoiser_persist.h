@@ -74,6 +74,7 @@ struct PersistArgs {
     float *h_save, *g_save, *sig_save, *tnh_save;   // per layer (stride act_stride floats): h, gate product, sigmoid, tanh
     size_t act_stride;
     unsigned long long *dbg;              // TIMING instantiation only: [tiles][NL + 2][12] cycle stamps of lane 0
+    int dbg_wave;                         //   ... of wave dbg_wave (MG_PERSIST_DBG_WAVE, default 0)
     int B, L, M, NL, tiles_per_b, post, clip, n_steps;
     int flags;                            // DP_F_*
     float rsNL;
@@ -124,7 +125,13 @@ __device__ __forceinline__ int dp_at(int ch, int col) { return (((ch >> 3) * NTC
 // on one accumulator back to back.  The iteration order over (chunk, tap) comes from IT.
 //   ap[i]: packed weights of block i (+ lane); k-group q of (chunk, tap) = (chunk * KW + tap) * 4 + g sits at ap[i][q * 64]
 //   tile:  k-interleaved LDS tile + (this lane's column of n-block 0 for tap 0) * 8 + hh * 4;  NTC: its columns
-template <int NMB, int NNB, int NTC, class IT, int DIST = (NMB * NNB >= 4 ? 2 : 3)>
+// DIST: how many k-groups ahead the weight fragments are requested.  3 everywhere since round 3: per-wave stamps
+// (MG_PERSIST_DBG_WAVE) show the second wave of every SIMD (waves 4-7) 14 % slower than the first in every GEMM phase
+// -- its requests queue behind the older wave's -- and the whole workgroup waits for it at the next barrier.
+#ifndef DP_DIST_BIG
+#define DP_DIST_BIG 3
+#endif
+template <int NMB, int NNB, int NTC, class IT, int DIST = (NMB * NNB >= 4 ? DP_DIST_BIG : 3)>
 __device__ __forceinline__ void dp_mfma_loop(f32x16 (&acc)[NMB][NNB], const f32x4 *const (&ap)[NMB], const float *__restrict__ tile)
 {
     static_assert(DIST >= 1 && DIST <= 3, "ring of 4 slots");
@@ -231,7 +238,7 @@ __device__ __forceinline__ bool dp_failed(unsigned *sync)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return __hip_atomic_load(sync + 1, DP_RLX_AGENT) != 0u;
 }
-#define DP_STAMP(k) do { if (TIMING && tid == 0) a.dbg[((size_t)tile * (a.NL + 2) + stamp_row) * 12 + (k)] = clock64(); } while (0)
+#define DP_STAMP(k) do { if (TIMING && tid == 64 * a.dbg_wave) a.dbg[((size_t)tile * (a.NL + 2) + stamp_row) * 12 + (k)] = clock64(); } while (0)
 
 // A reading step's conditioner projections (PersistArgs.cproj) come through LDS: wave w fetches the NT columns of its own
 // RW rows of layer l's [256, L] block straight into the (otherwise unused) conditioner tile region with LDS-direct loads
