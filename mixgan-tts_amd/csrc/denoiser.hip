@@ -750,11 +750,16 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
     // the MFMAs of its SIMD partner (measured at that shape: -0.2 ms; the non-saving forward is 8 % SLOWER that way --
     // half the MFMAs per fragment read -- and keeps 4 waves)
     bool wide32 = nt == 32 && save && (long)mg_cdiv(L, 32) * B <= 256;
+    bool eight64 = false;
     if (const char *ne = std::getenv("MG_PERSIST_NT")) {   // tests pin each width: 16, 32, 64, 328 = 32 frames x 8 waves
         const int f = std::atoi(ne);
         if (f == 32 || f == 64 || f == 328 || (f == 16 && has_p16 && !save)) {
             nt = f == 328 ? 32 : f;
             wide32 = f == 328;
+        }
+        if (f == 864) {   // 64-frame tiles as eight waves of 32 channels
+            nt = 64;
+            eight64 = true;
         }
     }
     if (nt == 16 && mg_cdiv(L, 16) > 128) nt = 32;
@@ -889,13 +894,32 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
         } else if (nt == 16) {
             if (vec4) hipLaunchKernelGGL(denoiser_persist16_kernel<true>, grid, dim3(256), 0, st, a);
             else hipLaunchKernelGGL(denoiser_persist16_kernel<false>, grid, dim3(256), 0, st, a);
-        } else if (nt == 64) {
+        } else if (nt == 64 && !eight64) {
+            // 64-frame tiles as FOUR waves of 64 channels: one wave per SIMD with the whole 512-entry register file
+            // (nobody to share the matrix pipe with, nobody's operands queueing behind an older wave's)
+#define MG_DP_LAUNCH4(V, T, S, CPM) \
+    hipLaunchKernelGGL((denoiser_persist_kernel<64, V, T, S, 4, CPM>), grid, dim3(256), 0, st, a)
+#define MG_DP_LAUNCH4V(T, S, CPM)             \
+    do {                                      \
+        if (vec4) MG_DP_LAUNCH4(true, T, S, CPM); \
+        else MG_DP_LAUNCH4(false, T, S, CPM);     \
+    } while (0)
+            const bool stamps = g_persist_dbg && vec4;
+            if (save) MG_DP_LAUNCH4V(false, true, 0);
+            else if (a.cproj) {
+                if (stamps) MG_DP_LAUNCH4(true, true, false, 2);
+                else MG_DP_LAUNCH4V(false, false, 2);
+            } else if (a.cproj_out) MG_DP_LAUNCH4V(false, false, 1);
+            else if (stamps) MG_DP_LAUNCH4(true, true, false, 0);
+            else MG_DP_LAUNCH4V(false, false, 0);
+#undef MG_DP_LAUNCH4V
+#undef MG_DP_LAUNCH4
+        } else if (nt == 64) {   // MG_PERSIST_NT=864: eight waves of 32 channels (the form up to round 3; A/B and tests)
             if (save) {
                 if (vec4) MG_DP_LAUNCH(64, true, false, true);
                 else MG_DP_LAUNCH(64, false, false, true);
             } else if (readp) {
-                if (g_persist_dbg && vec4) MG_DP_LAUNCH_R(64, true, true, 8);
-                else if (vec4) MG_DP_LAUNCH_R(64, true, false, 8);
+                if (vec4) MG_DP_LAUNCH_R(64, true, false, 8);
                 else MG_DP_LAUNCH_R(64, false, false, 8);
             } else if (g_persist_dbg && vec4) MG_DP_LAUNCH(64, true, true, false);
             else if (vec4) MG_DP_LAUNCH(64, true, false, false);
@@ -1148,8 +1172,12 @@ extern "C" int mg_denoiser_fwd_pair(const mg_denoiser_dims *d, const float *pack
     a.flags = 0;
     const bool vec4 = (L % 4 == 0) && (((uintptr_t)cond & 15) == 0) && (((uintptr_t)condB & 15) == 0);
     dim3 grid((unsigned)(tiles_per_b * 2 * Bh));
-    if (vec4) hipLaunchKernelGGL((denoiser_persist_kernel<64, true, false, true>), grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((denoiser_persist_kernel<64, false, false, true>), grid, dim3(512), 0, st, a);
+    const char *ne = std::getenv("MG_PERSIST_NT");
+    if (ne && std::atoi(ne) == 864) {   // eight waves of 32 channels (see denoiser_forward)
+        if (vec4) hipLaunchKernelGGL((denoiser_persist_kernel<64, true, false, true>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((denoiser_persist_kernel<64, false, false, true>), grid, dim3(512), 0, st, a);
+    } else if (vec4) hipLaunchKernelGGL((denoiser_persist_kernel<64, true, false, true, 4>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((denoiser_persist_kernel<64, false, false, true, 4>), grid, dim3(256), 0, st, a);
     MG_LAUNCH_CHECK();
     return MG_OK;
 }

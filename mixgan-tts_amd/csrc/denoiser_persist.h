@@ -13,8 +13,12 @@
 //     R2, the data is the flag) and runs the centre tap of GEMM 2 while they travel.  A workgroup executes exactly the
 //     algorithmic MFMAs (no halo MFMAs).
 // Two tile widths (same code, template parameter NT):
-//   NT = 64: 8 waves, wave w owns channels 32w..32w+31 x 64 frames; one workgroup per CU (139 KB of LDS); the weight
-//            stream is read once per 64 frames.  Used when it fills the chip (B x ceil(L/64) > 128 workgroups).
+//   NT = 64: 4 waves, wave w owns channels 64w..64w+63 x 64 frames -- ONE wave per SIMD with the whole 512-entry register
+//            file (x, the skip sum and GEMM 2's accumulators alone are 384 registers); one workgroup per CU (139 KB of
+//            LDS); the weight stream is read once per 64 frames.  Used when it fills the chip (B x ceil(L/64) > 128
+//            workgroups).  (Until round 3: 8 waves of 32 channels, two per SIMD; still there as MG_PERSIST_NT=864.  The
+//            second wave of every SIMD ran each GEMM phase 12-15 % slower than the first and the workgroup waited for it
+//            at every barrier: 350 -> 367 steps/s on the headline when each SIMD has one wave and nothing to wait for.)
 //   NT = 32: 4 waves, wave w owns channels 64w..64w+63 x 32 frames; two workgroups per CU (2 x 74 KB); twice the
 //            workgroups for small batches / single utterances, at twice the weight stream per frame.
 // LDS: condT 256 channels x NT columns    col j <-> frame l0+j     lives all layers
@@ -274,11 +278,11 @@ __device__ __forceinline__ void dp_cproj_fetch(const float *cp, float *cl, int w
 // that no kind of step carries another's registers (as run-time branches the stores cost the plain step 34 spilled
 // registers and 2 % of its time).
 template <int NT, bool VEC4, bool TIMING = false, bool SAVE = false, int NWV = NT / 8, int CPM = 0>
-__global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistArgs a)
+__global__ __launch_bounds__(NWV * 64, (NT == 64 && NWV == 4) ? 1 : 2) void denoiser_persist_kernel(PersistArgs a)
 {
     static_assert(!(CPM && SAVE), "the saving forward computes its projections and keeps none");
     constexpr bool READP = CPM == 2, WRITEP = CPM == 1;
-    static_assert((NT == 32 && (NWV == 4 || NWV == 8)) || (NT == 64 && NWV == 8),
+    static_assert((NT == 32 && (NWV == 4 || NWV == 8)) || (NT == 64 && (NWV == 8 || NWV == 4)),
                   "tile widths: 32 frames (4 waves, two workgroups per CU; or 8 waves, one per CU) or 64 (8 waves, one)");
     constexpr int NTHR = NWV * 64, NW = NWV;        // threads, waves
     constexpr bool TWO_PER_CU = NT == 32 && NWV == 4;
@@ -699,8 +703,10 @@ __global__ __launch_bounds__(NWV * 64, 2) void denoiser_persist_kernel(PersistAr
     }
     __syncthreads();
     const int mblocks = (a.M + 31) / 32;
-    if (w < mblocks * NNB) {   // output projection: one (32-row block, 32-column block) per wave (M <= 96 or 128)
-        const int mb = w / NNB, nb = w - mb * NNB;
+    // output projection: (32-row block, 32-column block) tasks dealt over the waves (M <= 96: 3 NNB tasks; one each, two for
+    // the first waves of the 4-wave 64-frame form)
+    for (int task = w; task < mblocks * NNB; task += NW) {
+        const int mb = task / NNB, nb = task - mb * NNB;
         f32x16 o[1][1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

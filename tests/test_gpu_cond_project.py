@@ -52,7 +52,7 @@ def test_cond_projection_matches_every_layers_conv(mg, manifest, tmp_path, B, L)
         assert_close(got[:, l * C:(l + 1) * C].cpu(), ref.float().cpu(), TOL, "layer %d" % l)
 
 
-@pytest.mark.parametrize("nt", [16, 216, 116, 32, 64, 328])
+@pytest.mark.parametrize("nt", [16, 216, 116, 32, 64, 328, 864])
 @pytest.mark.parametrize("ms", [False, True])
 def test_p_sample_reading_the_projection_is_bitwise_the_same(mg, manifest, tmp_path, monkeypatch, ms, nt):
     _pin_width(monkeypatch, nt)

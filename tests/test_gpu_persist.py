@@ -33,7 +33,7 @@ def _den(mg, manifest, tmp_path, ms=False):
 def _pin_width(monkeypatch, nt):
     """MG_PERSIST_NT pins a tile width; 16: teams of workgroups per tile where they fit (denoiser_team16.h: 4 members,
     else 2), 216: teams of 2 only, 116: 16-frame tiles with one workgroup per tile (denoiser_persist16.h) everywhere;
-    328: 32-frame tiles, 8 waves."""
+    328: 32-frame tiles, 8 waves; 64: 64-frame tiles as four waves (one per SIMD), 864: as eight waves of 32 channels."""
     monkeypatch.setenv("MG_PERSIST_NT", str(16 if nt in (116, 216) else nt))
     if nt == 116:
         monkeypatch.setenv("MG_PERSIST_TEAM", "0")
@@ -43,7 +43,7 @@ def _pin_width(monkeypatch, nt):
         monkeypatch.delenv("MG_PERSIST_TEAM", raising=False)
 
 
-@pytest.mark.parametrize("nt", [16, 216, 116, 32, 64, 328])
+@pytest.mark.parametrize("nt", [16, 216, 116, 32, 64, 328, 864])
 @pytest.mark.parametrize("ms", [False, True])
 def test_single_launch_forward_vs_oracle_and_per_layer_path(mg, manifest, tmp_path, monkeypatch, ms, nt):
     _pin_width(monkeypatch, nt)     # every tile width, whatever the heuristic would pick
