@@ -282,6 +282,13 @@ __global__ __launch_bounds__(NWV * 64, (NT == 64 && NWV == 4) ? 1 : 2) void deno
 {
     static_assert(!(CPM && SAVE), "the saving forward computes its projections and keeps none");
     constexpr bool READP = CPM == 2, WRITEP = CPM == 1;
+    // weight fragments of the layer's 2 x 2-block (and larger) loops: three k-groups ahead where two waves share a SIMD
+    // (dp_mfma_loop), two where one wave has it alone (requests in flight beyond what hides the latency only queue: a
+    // ring of eight with 4 / 5 / 7 ahead measured 359 / 354 / 343 steps/s against 366 at 3 and 369 at 2)
+#ifndef DP_DIST_SOLO
+#define DP_DIST_SOLO 2
+#endif
+    constexpr int DBIG = (NT == 64 && NWV == 4) ? DP_DIST_SOLO : DP_DIST_BIG;
     static_assert((NT == 32 && (NWV == 4 || NWV == 8)) || (NT == 64 && (NWV == 8 || NWV == 4)),
                   "tile widths: 32 frames (4 waves, two workgroups per CU; or 8 waves, one per CU) or 64 (8 waves, one)");
     constexpr int NTHR = NWV * 64, NW = NWV;        // threads, waves
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(NWV * 64, (NT == 64 && NWV == 4) ? 1 : 2) void deno
             const f32x4 *ap[MB];
 #pragma unroll
             for (int i = 0; i < MB; ++i) ap[i] = wc + (size_t)(MB * w + i) * 32 * 64 + lane;
-            dp_mfma_loop<MB, NNB, NC, DpIterK1>(acc1, ap, condT + c32 * 8 + hh * 4);
+            dp_mfma_loop<MB, NNB, NC, DpIterK1, (MB * NNB >= 4 ? DBIG : 3)>(acc1, ap, condT + c32 * 8 + hh * 4);
             if (WRITEP) {   // the first step of a sampling loop leaves the projections for the steps behind it
                 // uniform base + a 32-bit lane offset that is recomputed every layer (the opaque asm): kept live across
                 // the layer loop, 32 store addresses cost 34 spilled registers
@@ -567,7 +574,7 @@ __global__ __launch_bounds__(NWV * 64, (NT == 64 && NWV == 4) ? 1 : 2) void deno
             ap2[p][1] = w3 + (size_t)(2 * (MB * w + p) + 1) * 96 * 64 + lane;
         }
 #pragma unroll
-        for (int p = 0; p < MB; ++p) dp_mfma_loop<2, NNB, NH, DpIterCentre>(acc2[p], ap2[p], hT + c32 * 8 + hh * 4);
+        for (int p = 0; p < MB; ++p) dp_mfma_loop<2, NNB, NH, DpIterCentre, (2 * NNB >= 4 ? DBIG : 3)>(acc2[p], ap2[p], hT + c32 * 8 + hh * 4);
         DP_STAMP(4);
 
         // ------------------------------------------------------------ receive the halo columns
@@ -606,7 +613,7 @@ __global__ __launch_bounds__(NWV * 64, (NT == 64 && NWV == 4) ? 1 : 2) void deno
 
         // ------------------------------------------------------------ GEMM 2, taps 0 and 2; gate
 #pragma unroll
-        for (int p = 0; p < MB; ++p) dp_mfma_loop<2, NNB, NH, DpIterOuter>(acc2[p], ap2[p], hT + c32 * 8 + hh * 4);
+        for (int p = 0; p < MB; ++p) dp_mfma_loop<2, NNB, NH, DpIterOuter, (2 * NNB >= 4 ? DBIG : 3)>(acc2[p], ap2[p], hT + c32 * 8 + hh * 4);
         DP_STAMP(7);
         __syncthreads();   // every wave has read hT for the last time: g may overwrite it
         DP_STAMP(8);
@@ -655,7 +662,7 @@ __global__ __launch_bounds__(NWV * 64, (NT == 64 && NWV == 4) ? 1 : 2) void deno
                 ap[i] = wo + (size_t)(MB * w + i) * 32 * 64 + lane;            // x rows
                 ap[MB + i] = wo + (size_t)(8 + MB * w + i) * 32 * 64 + lane;   // skip rows
             }
-            dp_mfma_loop<2 * MB, NNB, NH, DpIterK1>(st, ap, hT + c32 * 8 + hh * 4);
+            dp_mfma_loop<2 * MB, NNB, NH, DpIterK1, (2 * MB * NNB >= 4 ? DBIG : 3)>(st, ap, hT + c32 * 8 + hh * 4);
         }
         DP_STAMP(11);
 #pragma unroll
