@@ -764,6 +764,9 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
     }
     if (nt == 16 && mg_cdiv(L, 16) > 128) nt = 32;
     if (nt != 32) wide32 = false;
+    // 32-frame tiles, not saving, at most one per CU: the one-workgroup-per-CU build (MG_PERSIST_SOLO=0: the two-per-CU one)
+    bool solo32 = nt == 32 && !wide32 && !save && (long)mg_cdiv(L, 32) * B <= mg_device_cus();
+    if (const char *se = std::getenv("MG_PERSIST_SOLO")) solo32 = solo32 && se[0] != '0';
     // ... and when even the 16-frame tiles number no more than a quarter of the CUs (one utterance of up to 1024 frames,
     // the configs[0] shape B=4, L<=256): four workgroups per tile, each owning 64 channels (denoiser_team16.h).  The
     // whole grid must be co-resident, one workgroup per CU.  MG_PERSIST_TEAM=0 keeps one workgroup per tile.
@@ -935,6 +938,19 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
             } else if (vec4) MG_DP_LAUNCH8(true, false);
             else MG_DP_LAUNCH8(false, false);
 #undef MG_DP_LAUNCH8
+        } else if (solo32) {
+            // at most one 32-frame tile per CU: the 4-wave form built for one workgroup per CU (512 registers per wave)
+#define MG_DP_LAUNCH_S(V, CPM) \
+    hipLaunchKernelGGL((denoiser_persist_kernel<32, V, false, false, 4, CPM, true>), grid, dim3(256), 0, st, a)
+            if (a.cproj) {
+                if (vec4) MG_DP_LAUNCH_S(true, 2);
+                else MG_DP_LAUNCH_S(false, 2);
+            } else if (a.cproj_out) {
+                if (vec4) MG_DP_LAUNCH_S(true, 1);
+                else MG_DP_LAUNCH_S(false, 1);
+            } else if (vec4) MG_DP_LAUNCH_S(true, 0);
+            else MG_DP_LAUNCH_S(false, 0);
+#undef MG_DP_LAUNCH_S
         } else {
             if (save) {
                 if (vec4) MG_DP_LAUNCH(32, true, false, true);

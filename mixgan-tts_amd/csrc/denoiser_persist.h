@@ -277,9 +277,12 @@ __device__ __forceinline__ void dp_cproj_fetch(const float *cp, float *cl, int w
 // (a.cproj_out), 2: reads them (a.cproj): its own instantiation without GEMM 1 and the conditioner tile.  Compile-time, so
 // that no kind of step carries another's registers (as run-time branches the stores cost the plain step 34 spilled
 // registers and 2 % of its time).
-template <int NT, bool VEC4, bool TIMING = false, bool SAVE = false, int NWV = NT / 8, int CPM = 0>
-__global__ __launch_bounds__(NWV * 64, (NT == 64 && NWV == 4) ? 1 : 2) void denoiser_persist_kernel(PersistArgs a)
+// SOLO (NT = 32, 4 waves): compiled for ONE workgroup per CU -- one wave per SIMD with the 512-entry register file -- for
+// launches of at most one 32-frame tile per CU (B = 8, L = 1000), where the second workgroup slot stays empty anyway.
+template <int NT, bool VEC4, bool TIMING = false, bool SAVE = false, int NWV = NT / 8, int CPM = 0, bool SOLO = false>
+__global__ __launch_bounds__(NWV * 64, ((NT == 64 && NWV == 4) || SOLO) ? 1 : 2) void denoiser_persist_kernel(PersistArgs a)
 {
+    static_assert(!SOLO || (NT == 32 && NWV == 4), "SOLO is the one-per-CU build of the 4-wave 32-frame form");
     static_assert(!(CPM && SAVE), "the saving forward computes its projections and keeps none");
     constexpr bool READP = CPM == 2, WRITEP = CPM == 1;
     // weight fragments of the layer's 2 x 2-block (and larger) loops: three k-groups ahead where two waves share a SIMD
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(NWV * 64, (NT == 64 && NWV == 4) ? 1 : 2) void deno
 #ifndef DP_DIST_SOLO
 #define DP_DIST_SOLO 2
 #endif
-    constexpr int DBIG = (NT == 64 && NWV == 4) ? DP_DIST_SOLO : DP_DIST_BIG;
+    constexpr int DBIG = ((NT == 64 && NWV == 4) || SOLO) ? DP_DIST_SOLO : DP_DIST_BIG;
     static_assert((NT == 32 && (NWV == 4 || NWV == 8)) || (NT == 64 && (NWV == 8 || NWV == 4)),
                   "tile widths: 32 frames (4 waves, two workgroups per CU; or 8 waves, one per CU) or 64 (8 waves, one)");
     constexpr int NTHR = NWV * 64, NW = NWV;        // threads, waves
