@@ -29,7 +29,11 @@ def _diffusion(mg, manifest, tmp_path, ms=False):
 
 
 def _pin_width(monkeypatch, nt):
-    monkeypatch.setenv("MG_PERSIST_NT", str(16 if nt in (116, 216) else nt))
+    monkeypatch.setenv("MG_PERSIST_NT", str(16 if nt in (116, 216) else 32 if nt == 232 else nt))
+    if nt == 232:      # 32-frame tiles, the two-workgroups-per-CU build also where one tile per CU would get the other one
+        monkeypatch.setenv("MG_PERSIST_SOLO", "0")
+    else:
+        monkeypatch.delenv("MG_PERSIST_SOLO", raising=False)
     if nt == 116:
         monkeypatch.setenv("MG_PERSIST_TEAM", "0")
     elif nt == 216:
@@ -52,7 +56,7 @@ def test_cond_projection_matches_every_layers_conv(mg, manifest, tmp_path, B, L)
         assert_close(got[:, l * C:(l + 1) * C].cpu(), ref.float().cpu(), TOL, "layer %d" % l)
 
 
-@pytest.mark.parametrize("nt", [16, 216, 116, 32, 64, 328, 864])
+@pytest.mark.parametrize("nt", [16, 216, 116, 32, 232, 64, 328, 864])
 @pytest.mark.parametrize("ms", [False, True])
 def test_p_sample_reading_the_projection_is_bitwise_the_same(mg, manifest, tmp_path, monkeypatch, ms, nt):
     _pin_width(monkeypatch, nt)

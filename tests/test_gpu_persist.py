@@ -34,7 +34,11 @@ def _pin_width(monkeypatch, nt):
     """MG_PERSIST_NT pins a tile width; 16: teams of workgroups per tile where they fit (denoiser_team16.h: 4 members,
     else 2), 216: teams of 2 only, 116: 16-frame tiles with one workgroup per tile (denoiser_persist16.h) everywhere;
     328: 32-frame tiles, 8 waves; 64: 64-frame tiles as four waves (one per SIMD), 864: as eight waves of 32 channels."""
-    monkeypatch.setenv("MG_PERSIST_NT", str(16 if nt in (116, 216) else nt))
+    monkeypatch.setenv("MG_PERSIST_NT", str(16 if nt in (116, 216) else 32 if nt == 232 else nt))
+    if nt == 232:      # 32-frame tiles, the two-workgroups-per-CU build also where one tile per CU would get the other one
+        monkeypatch.setenv("MG_PERSIST_SOLO", "0")
+    else:
+        monkeypatch.delenv("MG_PERSIST_SOLO", raising=False)
     if nt == 116:
         monkeypatch.setenv("MG_PERSIST_TEAM", "0")
     elif nt == 216:
@@ -43,7 +47,7 @@ def _pin_width(monkeypatch, nt):
         monkeypatch.delenv("MG_PERSIST_TEAM", raising=False)
 
 
-@pytest.mark.parametrize("nt", [16, 216, 116, 32, 64, 328, 864])
+@pytest.mark.parametrize("nt", [16, 216, 116, 32, 232, 64, 328, 864])
 @pytest.mark.parametrize("ms", [False, True])
 def test_single_launch_forward_vs_oracle_and_per_layer_path(mg, manifest, tmp_path, monkeypatch, ms, nt):
     _pin_width(monkeypatch, nt)     # every tile width, whatever the heuristic would pick
@@ -188,7 +192,7 @@ def test_in_kernel_noise_streams_never_repeat(mg, manifest, tmp_path):
     den.check()
 
 
-@pytest.mark.parametrize("nt", [16, 216, 116, 32, 64])
+@pytest.mark.parametrize("nt", [16, 216, 116, 32, 64, 864])
 def test_handoff_timeout_poisons_the_output_and_raises(mg, manifest, tmp_path, monkeypatch, nt):
     """A neighbour that never sends its edge column (test hook MG_PERSIST_FLAGS bit 1) with the wait bounded to a few
     polls: the kernel must drain (not hang), its output must be NaN (not a plausible mel), the failure must reach the
@@ -242,7 +246,7 @@ def test_sampling_raises_on_a_handoff_timeout(mg, manifest, tmp_path, monkeypatc
     assert torch.isfinite(gd.sampling(keep_trace=False)[0]).all()
 
 
-@pytest.mark.parametrize("nt", [16, 32, 64, 328])   # 328: 32-frame tiles, 8 waves (one workgroup per CU)
+@pytest.mark.parametrize("nt", [16, 32, 64, 328, 864])   # 328: 32-frame tiles, 8 waves (one workgroup per CU)
 def test_full_occupancy_handoffs_are_never_stale(mg, manifest, tmp_path, monkeypatch, nt):
     """B=16, L=1000: 512 workgroups, two per CU, every tile waiting on both neighbours in every layer.  The output must be
     bit-identical run after run, with or without a second stream saturating HBM beside it, and identical to what each
@@ -280,7 +284,7 @@ def test_full_occupancy_handoffs_are_never_stale(mg, manifest, tmp_path, monkeyp
     assert_close(first[:1].cpu(), ref, TOL, "vs oracle")
 
 
-@pytest.mark.parametrize("nt", [16, 32, 64, 328])   # 328: 32-frame tiles, 8 waves (one workgroup per CU)
+@pytest.mark.parametrize("nt", [16, 32, 64, 328, 864])   # 328: 32-frame tiles, 8 waves (one workgroup per CU)
 def test_more_tiles_than_slots_and_long_utterances(mg, manifest, tmp_path, monkeypatch, nt):
     """B=40, L=1000 = 1280 (640) workgroups on 512 (256) slots (later tiles start as earlier utterances finish), and
     L=4000 (125- / 63-tile chains): finite, deterministic, equal to each sample alone."""
