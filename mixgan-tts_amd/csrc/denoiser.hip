@@ -765,7 +765,9 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
     if (nt == 16 && mg_cdiv(L, 16) > 128) nt = 32;
     if (nt != 32) wide32 = false;
     // 32-frame tiles, not saving, at most one per CU: the one-workgroup-per-CU build (MG_PERSIST_SOLO=0: the two-per-CU one)
-    bool solo32 = nt == 32 && !wide32 && !save && (long)mg_cdiv(L, 32) * B <= mg_device_cus();
+    // (and an utterance's chain within a quarter of the slots THAT build has: one per CU)
+    bool solo32 = nt == 32 && !wide32 && !save && (long)mg_cdiv(L, 32) * B <= mg_device_cus() &&
+                  mg_cdiv(L, 32) <= mg_device_cus() / 4;
     if (const char *se = std::getenv("MG_PERSIST_SOLO")) solo32 = solo32 && se[0] != '0';
     // ... and when even the 16-frame tiles number no more than a quarter of the CUs (one utterance of up to 1024 frames,
     // the configs[0] shape B=4, L<=256): four workgroups per tile, each owning 64 channels (denoiser_team16.h).  The
