@@ -120,6 +120,33 @@ def test_sampling_loop_same_with_and_without_hoisting(mg, manifest, tmp_path, mo
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("ms", [False, True])
+def test_full_size_loop_hoisted_equals_step_by_step(mg, manifest, tmp_path, monkeypatch, ms):
+    """BASELINE configs[1] size (B=16, L=1000, T=4; 256 workgroups, every CU busy, every tile exchanging halos with both
+    neighbours while the first step streams 328 MB of projections out and the others stream them in): the whole trace of
+    the loop that shares its projections and step vectors equals the step-by-step loop's bit for bit, twice in a row (the
+    second loop overwrites the first one's buffer)."""
+    gd, _ = _diffusion(mg, manifest, tmp_path, ms)
+    B, L = 16, 1000
+    gen = torch.Generator(device="cuda").manual_seed(41)
+    gd.cond = torch.randn(B, 256, L, device="cuda", generator=gen)
+    gd.spk_emb = torch.randn(B, 256, device="cuda", generator=gen) if ms else None
+    start = torch.randn(B, 1, 80, L, device="cuda", generator=gen)
+    draws = [torch.randn(B, 1, 80, L, device="cuda", generator=gen).cpu().numpy() for _ in range(4)]
+    traces = {}
+    for hoist in ("1", "1", "0"):
+        monkeypatch.setenv("MG_COND_PREPROJECT", hoist)
+        gd.noise_fn = Tape(list(draws))
+        traces.setdefault(hoist, []).append(gd.sampling(noise=start.clone()))
+    gd.noise_fn = None
+    ref = traces["0"][0]
+    assert len(ref) == 5 and all(torch.isfinite(a).all() for a in ref)
+    for tr in traces["1"]:
+        for k, (a, b) in enumerate(zip(tr, ref)):
+            assert torch.equal(a, b), "step %d: %g" % (k, (a - b).abs().max().item())
+    gd.denoise_fn.check(sync=True)
+
+
 def test_long_loop_takes_its_step_vectors_in_chunks(mg, manifest, tmp_path, monkeypatch):
     """T = 100 steps at B = 64: 1024 // 64 = 16 steps per chunk; the trace equals the loop that computes every step's
     vectors by itself."""
