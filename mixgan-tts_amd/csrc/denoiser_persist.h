@@ -292,11 +292,15 @@ __global__ __launch_bounds__(NWV * 64, ((NT == 64 && NWV == 4) || SOLO) ? 1 : 2)
 #define DP_DIST_SOLO 2
 #endif
     constexpr int DBIG = ((NT == 64 && NWV == 4) || SOLO) ? DP_DIST_SOLO : DP_DIST_BIG;
+#ifndef DP_ONEPASS_WHEN
+#define DP_ONEPASS_WHEN (MB == 2 && ((NT == 64 && NWV == 4) || SOLO))
+#endif
     static_assert((NT == 32 && (NWV == 4 || NWV == 8)) || (NT == 64 && (NWV == 8 || NWV == 4)),
                   "tile widths: 32 frames (4 waves, two workgroups per CU; or 8 waves, one per CU) or 64 (8 waves, one)");
     constexpr int NTHR = NWV * 64, NW = NWV;        // threads, waves
     constexpr bool TWO_PER_CU = NT == 32 && NWV == 4;
-    constexpr int MB = 8 / NW;                      // 32-row blocks of the 256 channels per wave: 2 (NT = 32) or 1
+    constexpr int MB = 8 / NW;                      // 32-row blocks of the 256 channels per wave: 2 (4 waves) or 1
+    constexpr bool ONEPASS = DP_ONEPASS_WHEN;       // GEMM 2 over all of the wave's row blocks in one loop
     constexpr int NNB = NT / 32;                    // 32-column blocks per tile
     constexpr int NC = NT, NH = NT + 2;             // columns of the cond tile and of the h tile (k-interleaved: dp_at)
     __shared__ __attribute__((aligned(16))) float lds[RB_C * (NC + NH)];
@@ -576,8 +580,17 @@ __global__ __launch_bounds__(NWV * 64, ((NT == 64 && NWV == 4) || SOLO) ? 1 : 2)
             ap2[p][0] = w3 + (size_t)(2 * (MB * w + p)) * 96 * 64 + lane;
             ap2[p][1] = w3 + (size_t)(2 * (MB * w + p) + 1) * 96 * 64 + lane;
         }
+        // ONEPASS (one wave per SIMD, 512 registers): all four row blocks of the wave in one loop -- half the B-fragment
+        // reads and one pipeline fill per phase instead of two
+        if (ONEPASS) {
+            dp_mfma_loop<2 * MB, NNB, NH, DpIterCentre, DBIG>(reinterpret_cast<f32x16 (&)[2 * MB][NNB]>(acc2),
+                                                              reinterpret_cast<const f32x4 *const (&)[2 * MB]>(ap2),
+                                                              hT + c32 * 8 + hh * 4);
+        } else {
 #pragma unroll
-        for (int p = 0; p < MB; ++p) dp_mfma_loop<2, NNB, NH, DpIterCentre, (2 * NNB >= 4 ? DBIG : 3)>(acc2[p], ap2[p], hT + c32 * 8 + hh * 4);
+            for (int p = 0; p < MB; ++p)
+                dp_mfma_loop<2, NNB, NH, DpIterCentre, (2 * NNB >= 4 ? DBIG : 3)>(acc2[p], ap2[p], hT + c32 * 8 + hh * 4);
+        }
         DP_STAMP(4);
 
         // ------------------------------------------------------------ receive the halo columns
@@ -615,8 +628,15 @@ __global__ __launch_bounds__(NWV * 64, ((NT == 64 && NWV == 4) || SOLO) ? 1 : 2)
         DP_STAMP(6);
 
         // ------------------------------------------------------------ GEMM 2, taps 0 and 2; gate
+        if (ONEPASS) {
+            dp_mfma_loop<2 * MB, NNB, NH, DpIterOuter, DBIG>(reinterpret_cast<f32x16 (&)[2 * MB][NNB]>(acc2),
+                                                             reinterpret_cast<const f32x4 *const (&)[2 * MB]>(ap2),
+                                                             hT + c32 * 8 + hh * 4);
+        } else {
 #pragma unroll
-        for (int p = 0; p < MB; ++p) dp_mfma_loop<2, NNB, NH, DpIterOuter, (2 * NNB >= 4 ? DBIG : 3)>(acc2[p], ap2[p], hT + c32 * 8 + hh * 4);
+            for (int p = 0; p < MB; ++p)
+                dp_mfma_loop<2, NNB, NH, DpIterOuter, (2 * NNB >= 4 ? DBIG : 3)>(acc2[p], ap2[p], hT + c32 * 8 + hh * 4);
+        }
         DP_STAMP(7);
         __syncthreads();   // every wave has read hT for the last time: g may overwrite it
         DP_STAMP(8);
