@@ -121,7 +121,7 @@ __device__ __forceinline__ bool dt_gather(const dp_gu64 *buf, float *T, unsigned
 }
 
 template <bool VEC4, int TEAM>
-__global__ __launch_bounds__(1024 / TEAM, 2) void denoiser_team16_kernel(PersistArgs a)
+__global__ __launch_bounds__(1024 / TEAM, TEAM == 4 ? 1 : 2) void denoiser_team16_kernel(PersistArgs a)
 {
     static_assert(TEAM == 2 || TEAM == 4, "128 or 64 channels per workgroup");
     constexpr int NWV = 16 / TEAM, NTHR = 64 * NWV;   // one 16-row block of the 256 channels per wave
