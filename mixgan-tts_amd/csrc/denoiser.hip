@@ -783,9 +783,17 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
             else if (tiles16 * 2 <= mg_device_cus() && pin != 4) team = 2;
         }
     }
+    // 16-frame tiles, one workgroup per tile: built for one workgroup per CU (512 registers per wave) -- an utterance's
+    // chain within a quarter of THOSE slots, else 32-frame tiles
+    if (nt == 16 && team == 0 && mg_cdiv(L, 16) > mg_device_cus() / 4) {
+        nt = 32;
+        solo32 = !wide32 && !save && (long)mg_cdiv(L, 32) * B <= mg_device_cus() && mg_cdiv(L, 32) <= mg_device_cus() / 4;
+        if (const char *se = std::getenv("MG_PERSIST_SOLO")) solo32 = solo32 && se[0] != '0';
+    }
     const int tiles_per_b = mg_cdiv(L, nt);
-    // a quarter of the chip's workgroup slots (one per CU for the 8-wave forms, two for the 4-wave ones)
-    const int chain_cap = (nt == 64 || wide32) ? mg_device_cus() / 4 : mg_device_cus() / 2;
+    // a quarter of the chip's workgroup slots: one per CU for the builds with one wave per SIMD (64-frame tiles, the
+    // 8-wave 32-frame form, 16-frame tiles without teams, the one-per-CU 32-frame build), two for the 4-wave 32-frame form
+    const int chain_cap = (nt == 64 || wide32 || solo32 || (nt == 16 && team == 0)) ? mg_device_cus() / 4 : mg_device_cus() / 2;
     const bool persist = fused && !no_persist && !split && M <= 96 && NL >= 3 && tiles_per_b <= chain_cap;
     // the step-dependent vectors: this launch's own, unless the caller computed them for its whole sampling loop
     // (mg_denoiser_step_vectors; read in place by the single-launch kernels only)

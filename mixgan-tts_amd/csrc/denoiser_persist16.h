@@ -72,7 +72,7 @@ __device__ __forceinline__ void d16_store_block(float *T, int ch0, int col, int 
 }
 
 template <bool VEC4>
-__global__ __launch_bounds__(256, 2) void denoiser_persist16_kernel(PersistArgs a)
+__global__ __launch_bounds__(256, 1) void denoiser_persist16_kernel(PersistArgs a)
 {
     constexpr int NT = 16, NC = NT, NH = NT + 2;
     __shared__ __attribute__((aligned(16))) float lds[RB_C * (NC + NH)];

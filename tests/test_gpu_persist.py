@@ -119,8 +119,10 @@ def test_in_kernel_noise_is_standard_normal_and_fresh(mg, manifest, tmp_path):
         n = z.numel()
         assert abs(z.mean().item()) < 5.0 / n ** 0.5 and abs(z.var().item() - 1.0) < 0.02
         assert abs((z ** 3).mean().item()) < 0.05 and abs((z ** 4).mean().item() - 3.0) < 0.1
-        assert abs(torch.corrcoef(torch.stack([z.flatten()[:-1], z.flatten()[1:]]))[0, 1].item()) < 0.01
-    assert abs(torch.corrcoef(torch.stack([za.flatten(), zb.flatten()]))[0, 1].item()) < 0.01   # a fresh stream per call
+        # (n = 122,880: one sigma of a sample correlation is 0.0029 -- 0.015 is five of them; which stream a run draws
+        # depends on how many workspaces the process has made before)
+        assert abs(torch.corrcoef(torch.stack([z.flatten()[:-1], z.flatten()[1:]]))[0, 1].item()) < 0.015
+    assert abs(torch.corrcoef(torch.stack([za.flatten(), zb.flatten()]))[0, 1].item()) < 0.015   # a fresh stream per call
 
 
 def _corr(a, b):
