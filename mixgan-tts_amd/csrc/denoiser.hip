@@ -783,17 +783,14 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
             else if (tiles16 * 2 <= mg_device_cus() && pin != 4) team = 2;
         }
     }
-    // 16-frame tiles, one workgroup per tile: built for one workgroup per CU (512 registers per wave) -- an utterance's
-    // chain within a quarter of THOSE slots, else 32-frame tiles
-    if (nt == 16 && team == 0 && mg_cdiv(L, 16) > mg_device_cus() / 4) {
-        nt = 32;
-        solo32 = !wide32 && !save && (long)mg_cdiv(L, 32) * B <= mg_device_cus() && mg_cdiv(L, 32) <= mg_device_cus() / 4;
-        if (const char *se = std::getenv("MG_PERSIST_SOLO")) solo32 = solo32 && se[0] != '0';
-    }
+    // 16-frame tiles, one workgroup per tile: the one-workgroup-per-CU build (512 registers per wave) when the launch has
+    // at most one tile per CU and an utterance's chain fits in a quarter of THOSE slots, else the two-per-CU build
+    bool solo16 = nt == 16 && team == 0 && (long)mg_cdiv(L, 16) * B <= mg_device_cus() && mg_cdiv(L, 16) <= mg_device_cus() / 4;
+    if (const char *se = std::getenv("MG_PERSIST_SOLO")) solo16 = solo16 && se[0] != '0';
     const int tiles_per_b = mg_cdiv(L, nt);
     // a quarter of the chip's workgroup slots: one per CU for the builds with one wave per SIMD (64-frame tiles, the
     // 8-wave 32-frame form, 16-frame tiles without teams, the one-per-CU 32-frame build), two for the 4-wave 32-frame form
-    const int chain_cap = (nt == 64 || wide32 || solo32 || (nt == 16 && team == 0)) ? mg_device_cus() / 4 : mg_device_cus() / 2;
+    const int chain_cap = (nt == 64 || wide32 || solo32 || solo16) ? mg_device_cus() / 4 : mg_device_cus() / 2;
     const bool persist = fused && !no_persist && !split && M <= 96 && NL >= 3 && tiles_per_b <= chain_cap;
     // the step-dependent vectors: this launch's own, unless the caller computed them for its whole sampling loop
     // (mg_denoiser_step_vectors; read in place by the single-launch kernels only)
@@ -904,9 +901,12 @@ static int denoiser_forward(const mg_denoiser_dims *d, const float *packed, cons
             const dim3 tgrid((unsigned)(tiles_per_b * B * 2));
             if (vec4) hipLaunchKernelGGL((denoiser_team16_kernel<true, 2>), tgrid, dim3(512), 0, st, a);
             else hipLaunchKernelGGL((denoiser_team16_kernel<false, 2>), tgrid, dim3(512), 0, st, a);
+        } else if (nt == 16 && solo16) {
+            if (vec4) hipLaunchKernelGGL((denoiser_persist16_kernel<true, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((denoiser_persist16_kernel<false, true>), grid, dim3(256), 0, st, a);
         } else if (nt == 16) {
-            if (vec4) hipLaunchKernelGGL(denoiser_persist16_kernel<true>, grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL(denoiser_persist16_kernel<false>, grid, dim3(256), 0, st, a);
+            if (vec4) hipLaunchKernelGGL((denoiser_persist16_kernel<true, false>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((denoiser_persist16_kernel<false, false>), grid, dim3(256), 0, st, a);
         } else if (nt == 64 && !eight64) {
             // 64-frame tiles as FOUR waves of 64 channels: one wave per SIMD with the whole 512-entry register file
             // (nobody to share the matrix pipe with, nobody's operands queueing behind an older wave's)

@@ -71,8 +71,10 @@ __device__ __forceinline__ void d16_store_block(float *T, int ch0, int col, int 
     for (int r = 0; r < 4; ++r) base[4 * r] = val(r);
 }
 
-template <bool VEC4>
-__global__ __launch_bounds__(256, 1) void denoiser_persist16_kernel(PersistArgs a)
+// SOLO: built for one workgroup per CU (one wave per SIMD, up to 512 registers: 298 used, nothing spilled) -- for launches of
+// at most one tile per CU whose utterances' chains fit in a quarter of those slots; otherwise the two-per-CU build.
+template <bool VEC4, bool SOLO = false>
+__global__ __launch_bounds__(256, SOLO ? 1 : 2) void denoiser_persist16_kernel(PersistArgs a)
 {
     constexpr int NT = 16, NC = NT, NH = NT + 2;
     __shared__ __attribute__((aligned(16))) float lds[RB_C * (NC + NH)];
